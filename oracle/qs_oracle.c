@@ -1,0 +1,719 @@
+/*
+ * qs_oracle.c -- TEST INFRASTRUCTURE ONLY (see qs_oracle.h).
+ *
+ * A from-scratch plain-C restatement of the reference's scalar (NO_SIMD)
+ * arithmetic for the do_quantsmooth path.  Every function cites the reference
+ * file:line whose BEHAVIOUR it restates; no reference code is copied.  All
+ * float arithmetic is IEEE binary32, one rounding per operation, strictly in
+ * the written order (compile with -ffp-contract=off, no -ffast-math).
+ *
+ * Layout used here (ours, not the reference's): pixel planes carry a one-pixel
+ * apron on every side (pitch = width + 2) that holds clamp-to-edge copies,
+ * which is what the reference's border replication amounts to
+ * (reference quantsmooth.h:2612-2620).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <limits.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "qs_oracle.h"
+
+/* zigzag position -> natural (row-major) index; the JPEG standard's zigzag
+ * sequence (ITU T.81 Figure 5), same content as reference idct.h:24-33. */
+static const uint8_t zz2nat[64] = {
+	0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5,
+	12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+	35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+	58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63
+};
+
+/* A coefficient starts a new zigzag anti-diagonal (walking k = 63 -> 1) iff it
+ * lies on the block's top row or right column with odd/even parity as below;
+ * this reproduces the 14 refresh points of reference quantsmooth.h:313-322
+ * (k = 63,62,60,57,53,48,42,35,27,20,14,9,5,2). */
+static int starts_antidiagonal(int k) {
+	static const uint8_t first_k[14] = { 63, 62, 60, 57, 53, 48, 42, 35, 27, 20, 14, 9, 5, 2 };
+	int j;
+	for (j = 0; j < 14; j++) if (first_k[j] == k) return 1;
+	return 0;
+}
+
+/* float -> int32 as x86-64 cvttss2si does it: NaN and out-of-range give
+ * INT_MIN ("integer indefinite").  The reference's `int r = roundf(x)` relies
+ * on this (reference quantsmooth.h:1548-1549). */
+static int f2i_x86(float v) {
+	if (!(v >= -2147483648.0f && v < 2147483648.0f)) return INT_MIN;
+	return (int)v;
+}
+
+/* ------------------------------------------------------------------------ */
+/* A2: effective quant values.  reference quantsmooth.h:2497-2511            */
+void qso_quant_prep(const uint16_t q[64], uint16_t eff[64], int *all_le1, int *any_big) {
+	int i, acc = 0;
+	for (i = 0; i < 64; i++) {
+		acc |= q[i];
+		eff[i] = q[i] ? q[i] : 1; /* zero multipliers are treated as 1 */
+	}
+	if (all_le1) *all_le1 = acc <= 1;
+	if (any_big) *any_big = acc >= 0x800;
+}
+
+/* A5/A.6: the multiple of `div` nearest to `coef` (ties away from zero) and
+ * the integer interval that quantises to it.  Exact-division form
+ * (reference quantsmooth.h:338-341, 1552-1557).                             */
+void qso_interval(int coef, int div, int *orig, int *lo, int *hi) {
+	int half_dn = (div - 1) >> 1, half_up = div >> 1;
+	int o = (coef + (coef < 0 ? -half_up : half_up)) / div * div;
+	*orig = o;
+	*hi = o + (o < 0 ? half_up : half_dn);
+	*lo = o - (o > 0 ? half_up : half_dn);
+}
+
+/* The reciprocal-table form the reference actually executes
+ * (reference quantsmooth.h:2514-2539 builds x1/x2, :332-336 uses them).
+ * Returned for a KAT proving it equals qso_interval()'s `orig`.             */
+int qso_interval_recip(int coef, int div, int *orig) {
+	unsigned q = (unsigned)div, n = 0, t = q, x1;
+	int x2, a;
+	while (t > 1) { t >>= 1; n++; }
+	x1 = ((0x10000u << n) + q - 1) / q;
+	if (n) x1 |= x1 >> 16;
+	x2 = -0x8000 >> n;
+	a = (int16_t)(uint16_t)x1;
+	a = ((a * coef) >> 16) + coef;
+	a = (-a * (int)(int16_t)(uint16_t)x2 + 0x4000) >> 15;
+	*orig = a * div;
+	return *orig;
+}
+
+/* ------------------------------------------------------------------------ */
+/* A6: 13-bit fixed-point LL&M inverse DCT, +128, clamp to 0..255.
+ * reference idct.h:57-89 (butterfly), :468-539 (scalar passes).
+ * The reference's zero-AC shortcuts are exact special cases of the full
+ * butterfly (integer ring arithmetic), so they are not reproduced.          */
+#define C_0_298  2446
+#define C_0_390  3196
+#define C_0_541  4433
+#define C_0_765  6270
+#define C_0_899  7373
+#define C_1_175  9633
+#define C_1_501 12299
+#define C_1_847 15137
+#define C_1_961 16069
+#define C_2_053 16819
+#define C_2_562 20995
+#define C_3_072 25172
+
+static void idct8_int(const int32_t in[8], int32_t out[8]) {
+	/* all products/sums wrap mod 2^32 exactly like the reference's int32 code */
+	uint32_t e0, e1, e2, e3, s, o0, o1, o2, o3, p1, p2, p3, p4, p5;
+	uint32_t a = (uint32_t)in[0], b = (uint32_t)in[4];
+	uint32_t c = (uint32_t)in[2], d = (uint32_t)in[6];
+	uint32_t x7 = (uint32_t)in[7], x5 = (uint32_t)in[5], x3 = (uint32_t)in[3], x1 = (uint32_t)in[1];
+
+	s = (c + d) * C_0_541;
+	e2 = s - d * C_1_847;
+	e3 = s + c * C_0_765;
+	e0 = (a + b) << 13;
+	e1 = (a - b) << 13;
+
+	p1 = x7 + x1; p2 = x5 + x3; p3 = x7 + x3; p4 = x5 + x1;
+	p5 = (p3 + p4) * C_1_175;
+	o0 = x7 * C_0_298; o1 = x5 * C_2_053; o2 = x3 * C_3_072; o3 = x1 * C_1_501;
+	p1 *= C_0_899; p2 *= C_2_562; p3 *= C_1_961; p4 *= C_0_390;
+	p3 = p5 - p3; p4 = p5 - p4;
+	o0 += p3 - p1; o1 += p4 - p2; o2 += p3 - p2; o3 += p4 - p1;
+
+	out[0] = (int32_t)((e0 + e3) + o3); out[7] = (int32_t)((e0 + e3) - o3);
+	out[1] = (int32_t)((e1 + e2) + o2); out[6] = (int32_t)((e1 + e2) - o2);
+	out[2] = (int32_t)((e1 - e2) + o1); out[5] = (int32_t)((e1 - e2) - o1);
+	out[3] = (int32_t)((e0 - e3) + o0); out[4] = (int32_t)((e0 - e3) - o0);
+}
+
+/* arithmetic shift right with rounding term added in wrapping arithmetic */
+static int32_t descale(int32_t v, int32_t bias, int sh) {
+	return (int32_t)((uint32_t)v + (uint32_t)bias) >> sh;
+}
+
+void qso_idct_islow(const int16_t coef[64], uint8_t *out, int stride) {
+	int32_t ws[64], col[8], res[8];
+	int x, y, j;
+	for (x = 0; x < 8; x++) {           /* pass 1: columns, keep 2 extra bits */
+		for (j = 0; j < 8; j++) col[j] = coef[j * 8 + x];
+		idct8_int(col, res);
+		for (j = 0; j < 8; j++) ws[j * 8 + x] = descale(res[j], 1 << 10, 11);
+	}
+	for (y = 0; y < 8; y++) {           /* pass 2: rows, fold +128 and rounding */
+		idct8_int(ws + y * 8, res);
+		for (j = 0; j < 8; j++) {
+			int32_t v = descale(res[j], 257 << 17, 18);
+			out[y * stride + j] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------ */
+/* A3: float LL&M inverse DCT used only to derive the weight tables.
+ * reference idct.h:565-604.  Operation order is part of the contract.       */
+static void idct8_flt(const float *in, int is, float *out, int os, float post) {
+	float z1, z2, z3, z4, z5, t0, t1, t2, t3, t4, t5, t6, t7;
+	z2 = in[2 * is]; z3 = in[6 * is];
+	z1 = (z2 + z3) * 0.541196100f;
+	t2 = z1 - z3 * 1.847759065f;
+	t3 = z1 + z2 * 0.765366865f;
+	z2 = in[0]; z3 = in[4 * is];
+	t0 = z2 + z3; t1 = z2 - z3;
+	t4 = t0 + t3; t7 = t0 - t3;
+	t5 = t1 + t2; t6 = t1 - t2;
+	t0 = in[7 * is]; t1 = in[5 * is]; t2 = in[3 * is]; t3 = in[1 * is];
+	z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; z4 = t1 + t3;
+	z5 = (z3 + z4) * 1.175875602f;
+	t0 = t0 * 0.298631336f; t1 = t1 * 2.053119869f;
+	t2 = t2 * 3.072711026f; t3 = t3 * 1.501321110f;
+	z1 = z1 * 0.899976223f; z2 = z2 * 2.562915447f;
+	z3 = z3 * 1.961570560f; z4 = z4 * 0.390180644f;
+	z3 = z3 - z5; t0 = t0 - (z1 + z3); t2 = t2 - (z2 + z3);
+	z4 = z4 - z5; t1 = t1 - (z2 + z4); t3 = t3 - (z1 + z4);
+	if (post != 1.0f) {
+		out[0 * os] = (t4 + t3) * post; out[7 * os] = (t4 - t3) * post;
+		out[1 * os] = (t5 + t2) * post; out[6 * os] = (t5 - t2) * post;
+		out[2 * os] = (t6 + t1) * post; out[5 * os] = (t6 - t1) * post;
+		out[3 * os] = (t7 + t0) * post; out[4 * os] = (t7 - t0) * post;
+	} else {
+		out[0 * os] = t4 + t3; out[7 * os] = t4 - t3;
+		out[1 * os] = t5 + t2; out[6 * os] = t5 - t2;
+		out[2 * os] = t6 + t1; out[5 * os] = t6 - t1;
+		out[3 * os] = t7 + t0; out[4 * os] = t7 - t0;
+	}
+}
+
+void qso_idct_float(const float in[64], float out[64]) {
+	float ws[64]; int i;
+	for (i = 0; i < 8; i++) idct8_flt(in + i, 8, ws + i, 8, 1.0f);      /* columns */
+	for (i = 0; i < 8; i++) idct8_flt(ws + i * 8, 1, out + i * 8, 1, 0.125f); /* rows */
+}
+
+/* A8: float LL&M forward DCT.  reference idct.h:606-628, 895-916.           */
+static void fdct8_flt(const float *in, int is, float *out, int os, float post) {
+	float t0, t1, t2, t3, t4, t5, t6, t7, z1, z2, z3, z4, z5, r0, r1, r2, r3, r4, r5, r6, r7;
+	t0 = in[0] + in[7 * is];      t7 = in[0] - in[7 * is];
+	t1 = in[1 * is] + in[6 * is]; t6 = in[1 * is] - in[6 * is];
+	t2 = in[2 * is] + in[5 * is]; t5 = in[2 * is] - in[5 * is];
+	t3 = in[3 * is] + in[4 * is]; t4 = in[3 * is] - in[4 * is];
+	z1 = t0 + t3; z4 = t0 - t3; z2 = t1 + t2; z3 = t1 - t2;
+	r0 = z1 + z2; r4 = z1 - z2;
+	z1 = (z3 + z4) * 0.541196100f;
+	r2 = z1 + z4 * 0.765366865f;
+	r6 = z1 - z3 * 1.847759065f;
+	z1 = t4 + t7; z2 = t5 + t6; z3 = t4 + t6; z4 = t5 + t7;
+	z5 = (z3 + z4) * 1.175875602f;
+	t4 = t4 * 0.298631336f; t5 = t5 * 2.053119869f;
+	t6 = t6 * 3.072711026f; t7 = t7 * 1.501321110f;
+	z1 = z1 * 0.899976223f; z2 = z2 * 2.562915447f;
+	z3 = z3 * 1.961570560f - z5;
+	z4 = z4 * 0.390180644f - z5;
+	r7 = t4 - (z1 + z3); r5 = t5 - (z2 + z4);
+	r3 = t6 - (z2 + z3); r1 = t7 - (z1 + z4);
+	if (post != 1.0f) {
+		r0 *= post; r1 *= post; r2 *= post; r3 *= post;
+		r4 *= post; r5 *= post; r6 *= post; r7 *= post;
+	}
+	out[0] = r0; out[1 * os] = r1; out[2 * os] = r2; out[3 * os] = r3;
+	out[4 * os] = r4; out[5 * os] = r5; out[6 * os] = r6; out[7 * os] = r7;
+}
+
+void qso_fdct_float(const float in[64], float out[64]) {
+	float ws[64]; int i;
+	for (i = 0; i < 8; i++) fdct8_flt(in + i, 8, ws + i, 8, 1.0f);          /* columns */
+	for (i = 0; i < 8; i++) fdct8_flt(ws + i * 8, 1, out + i * 8, 1, 0.125f); /* rows */
+}
+
+/* ------------------------------------------------------------------------ */
+/* A3/A.4: per-coefficient weight tables.  reference quantsmooth.h:251-301.
+ * Layout per natural index i (floats):
+ *   [0..63]    horizontal diffs  T[p]-T[p+1]   (x == 7 -> 0)
+ *   [64..71]   top edge  T[x]*b ; [72..79] bottom T[56+x]*b
+ *   [80..87]   left edge T[8y]*b; [88..95] right  T[8y+7]*b
+ *   [96..159]  vertical diffs T[p]-T[p+8]      (y == 7 -> 0)
+ *   DIAGONALS: for y in 0..6: [160+16y+x] = T[p]-T[p+9], [168+16y+x] = T[p+1]-T[p+8]
+ *              (x == 7 -> 0); b = 4 instead of 2.                            */
+int qso_table_size(int flags) { return flags & QSO_DIAGONALS ? 272 : 160; }
+
+int qso_tables(int flags, float *out) {
+	int size = qso_table_size(flags), i, x, y;
+	float b = flags & QSO_DIAGONALS ? 4.0f : 2.0f;
+	for (i = 0; i < 64; i++) {
+		float imp[64], T[64], *w = out + (size_t)i * size;
+		memset(imp, 0, sizeof(imp)); imp[i] = 1.0f;
+		qso_idct_float(imp, T);
+		for (y = 0; y < 8; y++) for (x = 0; x < 8; x++) {
+			int p = y * 8 + x;
+			w[p] = x < 7 ? T[p] - T[p + 1] : 0.0f;
+			w[96 + p] = y < 7 ? T[p] - T[p + 8] : 0.0f;
+		}
+		for (x = 0; x < 8; x++) {
+			w[64 + x] = T[x] * b;
+			w[72 + x] = T[56 + x] * b;
+			w[80 + x] = T[8 * x] * b;
+			w[88 + x] = T[8 * x + 7] * b;
+		}
+		if (flags & QSO_DIAGONALS)
+			for (y = 0; y < 7; y++) for (x = 0; x < 8; x++) {
+				int p = y * 8 + x;
+				w[160 + 16 * y + x] = x < 7 ? T[p] - T[p + 9] : 0.0f;
+				w[168 + 16 * y + x] = x < 7 ? T[p + 1] - T[p + 8] : 0.0f;
+			}
+	}
+	return size;
+}
+
+/* tables are pure functions of (flags & DIAGONALS): cache both */
+static const float *get_tables(int flags) {
+	static float *cache[2];
+	int which = flags & QSO_DIAGONALS ? 1 : 0;
+	float *t;
+#ifdef _OPENMP
+#pragma omp critical(qso_tables)
+#endif
+	{
+		if (!cache[which]) {
+			t = (float*)malloc(sizeof(float) * 64 * qso_table_size(flags));
+			qso_tables(flags, t);
+			cache[which] = t;
+		}
+	}
+	return cache[which];
+}
+
+/* ------------------------------------------------------------------------ */
+/* A8: FDCT + round + clamp to each coefficient's quantisation interval.
+ * reference quantsmooth.h:343-347, 551-561.                                 */
+void qso_fdct_clamp(float *buf, int16_t *coef, const uint16_t eff_quant[64]) {
+	float f[64]; int i;
+	qso_fdct_float(buf, f);
+	for (i = 0; i < 64; i++) {
+		int orig, lo, hi, v;
+		qso_interval(coef[i], eff_quant[i], &orig, &lo, &hi);
+		v = f2i_x86(roundf(f[i]));
+		if (v > hi) v = hi;
+		if (v < lo) v = lo;
+		coef[i] = (int16_t)v;
+	}
+}
+
+/* A9: weighted 3x3 regression slope of B on A (weights 4/2/1).
+ * reference quantsmooth.h:894-913 and :2134-2156 (same arithmetic).         */
+static float regress_scale(const uint8_t *A, int sa, const uint8_t *B, int sb,
+		int32_t *wsumA, int32_t *wsumB) {
+	int32_t sA = 0, sB = 0, sAA = 0, sAB = 0; float scale;
+	int dx, dy;
+	for (dy = -1; dy <= 1; dy++) for (dx = -1; dx <= 1; dx++) {
+		int w = (dx ? 1 : 2) * (dy ? 1 : 2);
+		int32_t a = A[dy * sa + dx], b = B[dy * sb + dx];
+		sA += w * a; sB += w * b; sAA += w * a * a; sAB += w * a * b;
+	}
+	sAA = sAA * 16 - sA * sA;
+	sAB = sAB * 16 - sA * sB;
+	scale = (float)sAA;
+	if (sAA) scale = (float)sAB / scale;
+	if (scale < -16.0f) scale = -16.0f;
+	if (scale > 16.0f) scale = 16.0f;
+	*wsumA = sA; *wsumB = sB;
+	return scale;
+}
+
+/* ------------------------------------------------------------------------ */
+/* one smoothing term; reference quantsmooth.h:1519-1520 */
+#define TERM(diff, wgt) do { \
+	float d_ = (float)(diff), w_ = (wgt), t_ = R - fabsf(d_); \
+	t_ = t_ < 0 ? 0 : t_; t_ = t_ * t_; d_ = d_ * t_; w_ = w_ * t_; \
+	num = num + d_ * w_; den = den + w_ * w_; } while (0)
+
+/* A4 + A7 (+ A9, A10): per-block recovery.  reference quantsmooth.h:564-1849
+ * (scalar branches).  `image`/`image2` point at the block's top-left pixel in
+ * planes that are valid one pixel beyond the block on every side.           */
+void qso_block(int16_t *coef, const uint16_t q[64],
+		const uint8_t *image, const uint8_t *image2, int stride,
+		int flags, int luma) {
+	int x, y, k;
+
+	if (image2) { /* JOINT_YUV chroma predictor, reference :577-579, 893-921 */
+		float fb[64];
+		for (y = 0; y < 8; y++) for (x = 0; x < 8; x++) {
+			int32_t sA, sB; float a;
+			float scale = regress_scale(image2 + y * stride + x, stride,
+					image + y * stride + x, stride, &sA, &sB);
+			a = ((float)(image2[y * stride + x] * 16 - sA) * scale + (float)sB) * 0.0625f;
+			a = (a < 0 ? 0 : a) - 128.0f;
+			fb[y * 8 + x] = a > 128.0f ? 128.0f : a;
+		}
+		qso_fdct_clamp(fb, coef, q);
+	}
+
+	if (flags & QSO_LOW_QUALITY) { /* reference :924-938, 1161-1178 */
+		if (!image2) {
+			float fb[64], range = 0, c0 = 2, c1 = c0 * sqrtf(0.5f);
+			int sum = 0;
+			for (k = 1; k < 64; k++) {
+				int a = coef[k]; a = a < 0 ? -a : a;
+				range = range + (float)(q[k] * a); sum += a;
+			}
+			if (sum) range = range * (4.0f / (float)sum);
+			if (range > 128.0f) range = 128.0f;
+			range = roundf(range);
+			for (y = 0; y < 8; y++) for (x = 0; x < 8; x++) {
+				static const signed char nb[8][3] = { /* dx, dy, diagonal? */
+					{-1,-1,1}, {0,-1,0}, {1,-1,1}, {-1,0,0}, {1,0,0}, {-1,1,1}, {0,1,0}, {1,1,1} };
+				int a = image[y * stride + x], j;
+				float a0 = 0, an = 0;
+				for (j = 0; j < 8; j++) {
+					float t0 = (float)(a - image[(y + nb[j][1]) * stride + x + nb[j][0]]);
+					float t = range - fabsf(t0), aw;
+					t = t < 0 ? 0 : t; t = t * t; aw = (nb[j][2] ? c1 : c0) * t;
+					a0 = a0 + t0 * t * aw; an = an + aw * aw;
+				}
+				/* the reference keeps `a` as an int here: truncating update */
+				if (an > 0.0f) a = f2i_x86((float)a - a0 / an);
+				fb[y * 8 + x] = (float)(a - 128);
+			}
+			qso_fdct_clamp(fb, coef, q);
+		}
+	} else { /* main loop, reference :1396-1565 */
+		const float *tables = get_tables(flags);
+		int tsize = qso_table_size(flags), stale = 1;
+		uint8_t px[64], top[8], bot[8], lft[8], rgt[8];
+		for (x = 0; x < 8; x++) {
+			top[x] = image[x - stride]; bot[x] = image[x + 8 * stride];
+			lft[x] = image[x * stride - 1]; rgt[x] = image[x * stride + 8];
+		}
+		for (k = 63; k > 0; k--) {
+			int i = zz2nat[k], r;
+			const float *w = tables + (size_t)i * tsize;
+			float num = 0, den = 0, R = (float)(q[i] * 2);
+			if (stale && starts_antidiagonal(k)) { qso_idct_islow(coef, px, 8); stale = 0; }
+
+			if (i & 7) /* coefficient varies horizontally */
+				for (y = 0; y < 8; y++) for (x = 0; x < 7; x++)
+					TERM(px[y * 8 + x] - px[y * 8 + x + 1], w[y * 8 + x]);
+			for (x = 0; x < 8; x++) TERM(px[x] - top[x], w[64 + x]);
+			for (x = 0; x < 8; x++) TERM(px[56 + x] - bot[x], w[72 + x]);
+			for (y = 0; y < 8; y++) TERM(px[y * 8] - lft[y], w[80 + y]);
+			for (y = 0; y < 8; y++) TERM(px[y * 8 + 7] - rgt[y], w[88 + y]);
+			if (i > 7) /* coefficient varies vertically */
+				for (y = 0; y < 7; y++) for (x = 0; x < 8; x++)
+					TERM(px[y * 8 + x] - px[y * 8 + x + 8], w[96 + y * 8 + x]);
+			if (flags & QSO_DIAGONALS)
+				for (y = 0; y < 7; y++) for (x = 0; x < 7; x++) {
+					TERM(px[y * 8 + x] - px[y * 8 + x + 9], w[160 + 16 * y + x]);
+					TERM(px[y * 8 + x + 1] - px[y * 8 + x + 8], w[168 + 16 * y + x]);
+				}
+
+			r = f2i_x86(roundf(num / den));
+			if (r) {
+				int orig, lo, hi, c0 = coef[i], v;
+				qso_interval(c0, q[i], &orig, &lo, &hi);
+				v = (int)((unsigned)c0 - (unsigned)r); /* wraps like x86 */
+				if (v > hi) v = hi;
+				if (v < lo) v = lo;
+				coef[i] = (int16_t)v;
+				stale |= v ^ c0;
+			}
+		}
+	}
+
+	/* A7 rebalance, reference :1566-1568, 1823-1848 */
+	if (flags & QSO_NO_REBALANCE) return;
+	if (!luma && (flags & QSO_NO_REBALANCE_UV)) return;
+	{
+		int64_t m0 = 0, m1 = 0; int orig[64], lo[64], hi[64];
+		for (k = 1; k < 64; k++) {
+			qso_interval(coef[k], q[k], &orig[k], &lo[k], &hi[k]);
+			m0 += coef[k] * orig[k]; m1 += orig[k] * orig[k];
+		}
+		if (m1 > m0) {
+			int mul = (int)(((m1 << 13) + (m0 >> 1)) / m0);
+			for (k = 1; k < 64; k++) {
+				int v = (coef[k] * mul + 0x1000) >> 13;
+				if (v > hi[k]) v = hi[k];
+				if (v < lo[k]) v = lo[k];
+				coef[k] = (int16_t)v;
+			}
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------ */
+/* plane helpers (our layout: apron of 1, pitch = w + 2)                      */
+typedef struct { uint8_t *base; int w, h, pitch; } plane_t;
+
+static int plane_alloc(plane_t *p, int w, int h) {
+	p->w = w; p->h = h; p->pitch = w + 2;
+	p->base = (uint8_t*)malloc((size_t)(h + 2) * p->pitch + 16);
+	return p->base != NULL;
+}
+static uint8_t *plane_px(const plane_t *p, int x, int y) {
+	return p->base + (size_t)(y + 1) * p->pitch + x + 1;
+}
+/* clamp-to-edge apron, reference quantsmooth.h:2612-2620 (A.10) */
+static void plane_apron(plane_t *p) {
+	int y;
+	for (y = 0; y < p->h; y++) {
+		*plane_px(p, -1, y) = *plane_px(p, 0, y);
+		*plane_px(p, p->w, y) = *plane_px(p, p->w - 1, y);
+	}
+	memcpy(plane_px(p, -1, -1), plane_px(p, -1, 0), p->pitch);
+	memcpy(plane_px(p, -1, p->h), plane_px(p, -1, p->h - 1), p->pitch);
+}
+
+/* A11: box-downsampled luma at chroma resolution, replicated out to the
+ * chroma plane size.  reference quantsmooth.h:2753-2815.                     */
+static void make_luma_lowres(const plane_t *Y, plane_t *L, int ws, int hs) {
+	int w1 = (Y->w + ws - 1) / ws, h1 = (Y->h + hs - 1) / hs, x, y;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic) private(x)
+#endif
+	for (y = 0; y < h1; y++) {
+		int bh = Y->h - y * hs; if (bh > hs) bh = hs;
+		for (x = 0; x < w1; x++) {
+			int bw = Y->w - x * ws, xx, yy, sum = 0, n;
+			if (bw > ws) bw = ws;
+			n = bw * bh;
+			for (yy = 0; yy < bh; yy++) for (xx = 0; xx < bw; xx++)
+				sum += *plane_px(Y, x * ws + xx, y * hs + yy);
+			/* 2x2 fast path (a+2)>>2 equals (sum + n/2)/n for n == 4 */
+			*plane_px(L, x, y) = (uint8_t)((sum + n / 2) / n);
+		}
+	}
+	for (y = 0; y < h1; y++) {
+		uint8_t last = *plane_px(L, w1 - 1, y);
+		*plane_px(L, -1, y) = *plane_px(L, 0, y);
+		for (x = w1; x <= L->w; x++) *plane_px(L, x, y) = last;
+	}
+	memcpy(plane_px(L, -1, -1), plane_px(L, -1, 0), L->pitch);
+	for (y = h1; y <= L->h; y++) memcpy(plane_px(L, -1, y), plane_px(L, -1, h1 - 1), L->pitch);
+}
+
+/* A12: chroma upsampling guided by full-resolution luma.
+ * reference quantsmooth.h:1851-1864, 2133-2158, 2363-2393 (per 8-row strip)
+ * and :2724-2730 (strip loop + bottom replicate).
+ * C = low-res chroma plane, L = low-res luma, Y = full-res luma,
+ * out = full-res chroma pixels (pitch st, ww x hh valid).                     */
+static void upsample_chroma(const plane_t *C, const plane_t *L, const plane_t *Y,
+		uint8_t *out, int st, int ww, int hh, int w1, int h1, int ws, int hs) {
+	int y;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic)
+#endif
+	for (y = 0; y < h1; y++) {
+		int x, xx, yy, xend = (w1 + 7) & ~7;
+		for (x = 0; x < xend; x++) {
+			int32_t sA, sB;
+			float scale = regress_scale(plane_px(L, x, y), L->pitch, plane_px(C, x, y), C->pitch, &sA, &sB);
+			float offset = (float)*plane_px(C, x, y) - (float)*plane_px(L, x, y) * scale + 0.5f;
+			for (yy = 0; yy < hs; yy++) for (xx = 0; xx < ws; xx++) {
+				int v = f2i_x86((float)*plane_px(Y, x * ws + xx, y * hs + yy) * scale + offset);
+				out[(size_t)(y * hs + yy) * st + x * ws + xx] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+			}
+		}
+		/* Right-edge replicate.  The reference applies it only to the rows of
+		 * the FIRST 8-row strip: its loop `for (yy = y0*hs; yy < y1*hs; ...)`
+		 * runs with y1 already made relative to y0 and `mem` already advanced
+		 * (reference quantsmooth.h:1860-1861, 2390-2393), so it is empty for
+		 * y0 >= 8.  Later strips keep the computed values.  Reproduced as is. */
+		if (y < 8)
+			for (yy = 0; yy < hs; yy++) {
+				uint8_t *row = out + (size_t)(y * hs + yy) * st;
+				for (x = w1 * ws; x < ww; x++) row[x] = row[w1 * ws - 1];
+			}
+	}
+	for (y = h1 * hs; y < hh; y++)
+		memcpy(out + (size_t)y * st, out + (size_t)(h1 * hs - 1) * st, st);
+}
+
+void qso_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------ */
+/* A1: the plane driver on flat arrays.  reference quantsmooth.h:2404-2878.   */
+int qso_do_quantsmooth(qso_job *job, int flags, int niter, int threads,
+		int progprec, qso_progress_fn progress, void *userdata) {
+	int ci, stop = 0, need_lowres = 0, i;
+	int prog_next = 0, prog_max = 0, prog_thr = 0;
+	plane_t Yfull = {0, 0, 0, 0}, Llow = {0, 0, 0, 0};
+	int have_Yfull = 0, have_Llow = 0, Llow_is_Y = 0;
+	int16_t *up[2] = { NULL, NULL };
+#ifdef _OPENMP
+	int old_threads = -1;
+#endif
+
+	job->up_wblk = job->up_hblk = 0; job->coef_up[0] = job->coef_up[1] = NULL;
+	job->out_hsamp0 = job->hsamp[0]; job->out_vsamp0 = job->vsamp[0];
+
+	/* reference :2447-2453 */
+	if ((flags & (QSO_JOINT_YUV | QSO_UPSAMPLE_UV)) && job->colorspace == 3 &&
+			job->hsamp[1] == 1 && job->vsamp[1] == 1 && job->hsamp[2] == 1 && job->vsamp[2] == 1)
+		need_lowres = 1;
+	if (niter < 0) niter = 0;
+	if (niter > 100) niter = 100;
+	if (niter <= 0 && !((flags & QSO_UPSAMPLE_UV) && need_lowres)) return 0;
+
+#ifdef _OPENMP
+	if (threads >= 0) {
+		old_threads = omp_get_max_threads();
+		omp_set_num_threads(threads ? threads : omp_get_num_procs());
+	}
+#else
+	(void)threads;
+#endif
+
+	if (progress) { /* reference :2474-2482 */
+		for (ci = 0; ci < job->ncomp; ci++) prog_max += job->hblk[ci] * job->vsamp[ci] * niter;
+		if (progprec == 0) progprec = 20;
+		if (progprec < 0) progprec = prog_max;
+		prog_thr = (int)((unsigned)(prog_max + progprec - 1) / (unsigned)progprec);
+	}
+
+	for (ci = 0; ci < job->ncomp; ci++) {
+		uint16_t q[64]; const uint16_t *rawq = job->quant[ci];
+		int wb = job->wblk[ci], hb = job->hblk[ci];
+		int16_t *coefs = job->coef[ci];
+		int extra = 0, iters = niter, all_le1, any_big, it, by;
+		int prog_cur = prog_next, prog_inc = job->vsamp[ci];
+		int luma = !ci || job->colorspace != 3;
+		plane_t P; int have_P = 0;
+
+		prog_next += hb * prog_inc * niter;
+		if (!job->has_quant[ci]) continue;
+		if (have_Yfull || (!ci && need_lowres)) extra = 1;
+		qso_quant_prep(rawq, q, &all_le1, &any_big);
+		if (all_le1) iters = 0;
+		if (any_big) stop = 1;
+		if (iters + extra == 0) continue;
+
+		if (!stop) have_P = plane_alloc(&P, wb * 8, hb * 8);
+		if (!have_P) { /* dequantise only, reference :2551-2566 */
+			for (by = 0; by < hb; by++) for (i = 0; i < wb * 64; i++) {
+				int16_t *c = coefs + (size_t)by * wb * 64 + i;
+				*c = (int16_t)(*c * rawq[i & 63]);
+			}
+			continue;
+		}
+
+		for (it = 0; it < iters + extra; it++) {
+			int bad = 0;
+			/* pass A: (dequantise +) IDCT to the plane, reference :2589-2609 */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic) reduction(|:bad)
+#endif
+			for (by = 0; by < hb; by++) {
+				int bx, j;
+				for (bx = 0; bx < wb; bx++) {
+					int16_t *c = coefs + ((size_t)by * wb + bx) * 64;
+					if (!it)
+						for (j = 0; j < 64; j++) {
+							int v = c[j] * rawq[j];
+							c[j] = (int16_t)v;
+							if (v < -0x800 || v > 0x7ff) bad = 1;
+						}
+					qso_idct_islow(c, plane_px(&P, bx * 8, by * 8), P.pitch);
+				}
+			}
+			if (bad) { stop = 1; break; }
+			plane_apron(&P);
+			if (it == iters) break;
+
+			/* pass B: per-block recovery, reference :2627-2640 */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic)
+#endif
+			for (by = 0; by < hb; by++) {
+				int bx;
+				for (bx = 0; bx < wb; bx++) {
+					const uint8_t *p2 = NULL;
+					if (have_Llow && (flags & QSO_JOINT_YUV))
+						p2 = plane_px(&Llow, bx * 8, by * 8);
+					/* L and the chroma plane share dimensions, hence one stride */
+					qso_block(coefs + ((size_t)by * wb + bx) * 64, q,
+							plane_px(&P, bx * 8, by * 8), p2, P.pitch, flags, luma);
+				}
+			}
+			if (progress) { /* reference :2656-2664 */
+				int cur = prog_cur += hb * prog_inc;
+				if (cur >= prog_thr) {
+					cur = (int)((int64_t)progprec * cur / prog_max);
+					prog_thr = (int)(((int64_t)(cur + 1) * prog_max + progprec - 1) / progprec);
+					stop = progress(userdata, cur, progprec);
+				}
+				if (stop) break;
+			}
+		}
+
+		/* A13: final clamp, reference :2668-2689 */
+		for (by = 0; by < hb; by++) for (i = 0; i < wb * 64; i++) {
+			int16_t *c = coefs + (size_t)by * wb * 64 + i;
+			if (*c > 1023) *c = 1023;
+			if (*c < -1023) *c = -1023;
+		}
+
+		if (!stop && have_Yfull) { /* A12, reference :2691-2752 */
+			int ws = job->hsamp[0], hs = job->vsamp[0];
+			int w1 = (job->image_width + ws - 1) / ws, h1 = (job->image_height + hs - 1) / hs;
+			int uwb = job->wblk[0], uhb = job->hblk[0];
+			int ww = uwb * 8, hh = uhb * 8;
+			int st = ((w1 + 8) & -8) * ws, h2 = ((h1 + 8) & -8) * hs;
+			uint8_t *mem = (uint8_t*)malloc((size_t)h2 * st);
+			int16_t *dst = (int16_t*)calloc((size_t)uwb * uhb * 64 + 64, sizeof(int16_t));
+			up[ci - 1] = dst;
+			if (mem && dst) {
+				upsample_chroma(&P, &Llow, &Yfull, mem, st, ww, hh, w1, h1, ws, hs);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic)
+#endif
+				for (by = 0; by < uhb; by++) {
+					int bx, x, y;
+					for (bx = 0; bx < uwb; bx++) {
+						float fb[64], fo[64];
+						for (y = 0; y < 8; y++) for (x = 0; x < 8; x++)
+							fb[y * 8 + x] = (float)(mem[(size_t)(by * 8 + y) * st + bx * 8 + x] - 128);
+						qso_fdct_float(fb, fo);
+						for (x = 0; x < 64; x++)
+							dst[((size_t)by * uwb + bx) * 64 + x] = (int16_t)f2i_x86(roundf(fo[x]));
+					}
+				}
+			}
+			free(mem);
+		} else if (!stop && !ci && need_lowres) { /* A11, reference :2753-2815 */
+			int ws = job->hsamp[0], hs = job->vsamp[0];
+			if (ws == 1 && hs == 1) {
+				Llow = P; have_Llow = 1; Llow_is_Y = 1; have_P = 0;
+			} else {
+				if (flags & QSO_UPSAMPLE_UV) { Yfull = P; have_Yfull = 1; have_P = 0; }
+				if (plane_alloc(&Llow, job->wblk[1] * 8, job->hblk[1] * 8)) {
+					have_Llow = 1;
+					make_luma_lowres(have_Yfull ? &Yfull : &P, &Llow, ws, hs);
+				}
+			}
+		}
+		if (have_P) free(P.base);
+	}
+
+#ifdef _OPENMP
+	if (old_threads > 0) omp_set_num_threads(old_threads);
+#endif
+	if (have_Llow) free(Llow.base);
+	if (have_Yfull && !Llow_is_Y) free(Yfull.base);
+
+	if (stop || !have_Yfull) {
+		free(up[0]); free(up[1]);
+	} else { /* reference :2836-2849 */
+		job->coef_up[0] = up[0]; job->coef_up[1] = up[1];
+		job->up_wblk = job->wblk[0]; job->up_hblk = job->hblk[0];
+		job->out_hsamp0 = job->out_vsamp0 = 1;
+	}
+	/* reference :2851-2859 */
+	for (ci = 0; ci < job->ncomp; ci++)
+		if (job->has_quant[ci]) for (i = 0; i < 64; i++) job->quant[ci][i] = 1;
+	return stop;
+}
