@@ -1,0 +1,116 @@
+/*
+ * jpegqs_hip.h -- flat C ABI of the MI355X (gfx950) implementation of
+ * jpeg-quantsmooth's coefficient-recovery path.
+ *
+ * Two layers, both plain C (pointers + sizes, no libjpeg / torch types):
+ *
+ *  1. JOB LAYER  qs_hip_do_quantsmooth(): the whole of the reference's
+ *     do_quantsmooth() (reference quantsmooth.h:2404-2878) on caller-owned HOST
+ *     arrays -- same inputs (JCOEF blocks as jpeg_read_coefficients() returns
+ *     them, quant tables, sampling factors, flags/niter/progress), same outputs
+ *     (blocks rewritten in place, quant tables set to 1, return value = the
+ *     reference's `stop`).  The libjpeg-facing drop-in (include/libjpegqs.h,
+ *     csrc/jpegqs_shim.c) gathers JBLOCKROWs into these arrays and calls this.
+ *
+ *  2. PLANE LAYER  qs_hip_*_plane(): the individual GPU passes on DEVICE
+ *     pointers and an explicit HIP stream, for callers that keep data resident
+ *     in HBM (bench.py, the multi-GPU band driver, pipelines that decode on the
+ *     GPU).  One call = one kernel launch, asynchronous on `stream`.
+ *
+ * All functions return 0 on success and a negative QS_HIP_E* code on failure;
+ * qs_hip_last_error() gives the message.  There is no CPU fallback: without a
+ * usable HIP device every compute entry point fails with QS_HIP_ENODEV.
+ */
+#ifndef JPEGQS_HIP_H
+#define JPEGQS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QS_HIP_MAXC 4
+
+enum {
+	QS_HIP_OK = 0,
+	QS_HIP_ENODEV = -1,   /* no HIP device / runtime error */
+	QS_HIP_EINVAL = -2,   /* bad argument */
+	QS_HIP_ENOMEM = -3,   /* host or device allocation failed */
+	QS_HIP_ENOTSUP = -4   /* flag combination not implemented on the GPU yet */
+};
+
+/* ---- job layer ---------------------------------------------------------- */
+
+/* One image, as do_quantsmooth() sees it (reference quantsmooth.h:2423-2427,
+ * 2447-2451, 2488-2493).  Layout is shared with the test oracles. */
+typedef struct {
+	int32_t ncomp;                     /* cinfo->num_components, 1..4 */
+	int32_t colorspace;                /* cinfo->jpeg_color_space (1 gray, 3 YCbCr, ...) */
+	int32_t image_width, image_height; /* cinfo->image_width/height */
+	int32_t wblk[QS_HIP_MAXC];         /* comp_info[ci].width_in_blocks */
+	int32_t hblk[QS_HIP_MAXC];         /* comp_info[ci].height_in_blocks */
+	int32_t hsamp[QS_HIP_MAXC];        /* comp_info[ci].h_samp_factor */
+	int32_t vsamp[QS_HIP_MAXC];        /* comp_info[ci].v_samp_factor */
+	int32_t has_quant[QS_HIP_MAXC];    /* comp_info[ci].quant_table != NULL */
+	uint16_t quant[QS_HIP_MAXC][64];   /* quantval[], natural order; set to 1 on return */
+	int16_t *coef[QS_HIP_MAXC];        /* hblk*wblk blocks of 64 JCOEF, in/out */
+	/* UPSAMPLE_UV only: replacement chroma arrays at luma resolution
+	 * (reference :2696-2703, 2836-2849); malloc'd, release with qs_hip_free() */
+	int16_t *coef_up[2];
+	int32_t up_wblk, up_hblk;          /* 0 when chroma was not replaced */
+	int32_t out_hsamp0, out_vsamp0;    /* component 0 sampling factors on return */
+} qs_hip_job;
+
+/* opts->progress of reference libjpegqs.h:41-45 */
+typedef int (*qs_hip_progress_fn)(void *userdata, int cur, int max);
+
+/* flags: JPEGQS_* algorithm bits (reference libjpegqs.h:16-23); niter, progprec,
+ * progress, userdata: the jpegqs_control_t fields of the same names.
+ * Returns the reference's `stop` (0 done, 1 cancelled/rejected input) or <0. */
+int qs_hip_do_quantsmooth(qs_hip_job *job, int flags, int niter, int progprec,
+		qs_hip_progress_fn progress, void *userdata);
+void qs_hip_free(void *p);
+
+/* ---- plane layer (device pointers, async on `stream`) --------------------- */
+
+int qs_hip_device_count(void);
+const char *qs_hip_last_error(void);
+
+/* bytes of the per-component constant block; pixel-plane pitch and size */
+size_t qs_hip_consts_bytes(void);
+size_t qs_hip_plane_pitch(int wblk);
+size_t qs_hip_plane_bytes(int wblk, int hblk);
+/* byte offset of pixel (x = -QS apron .. , y) helpers for halo exchange:
+ * row y (y = -1 .. hblk*8) of the plane starts at qs_hip_plane_row_offset(wblk, y)
+ * and is qs_hip_plane_pitch(wblk) bytes long (apron columns included). */
+size_t qs_hip_plane_row_offset(int wblk, int y);
+
+/* Build the constant block for one component on the host (quant-derived values,
+ * reference :2497-2540, and the weight tables, reference :251-301) into
+ * `host_out` (qs_hip_consts_bytes() bytes); the caller copies it to the device. */
+int qs_hip_consts_build(void *host_out, const uint16_t quant[64], int flags);
+
+/* pass A: [first: dequantise + range check ->*d_status |= 1] IDCT into the plane
+ * (reference :2589-2620).  rep_top/rep_bot: fill the y=-1 / y=h apron rows by
+ * replication (0 when they are halo rows owned by a neighbouring band). */
+int qs_hip_idct_plane(const void *d_consts, int16_t *d_coef, uint8_t *d_plane,
+		int wblk, int hblk, int first, int rep_top, int rep_bot,
+		int32_t *d_status, void *stream);
+
+/* pass B: per-block recovery loop + rebalance (+ final clamp)
+ * (reference :2627-2640 -> quantsmooth_block :564-1849; clamp :2668-2689).
+ * Supported here: flags & (DIAGONALS | NO_REBALANCE | NO_REBALANCE_UV). */
+int qs_hip_smooth_plane(const void *d_consts, int16_t *d_coef, const uint8_t *d_plane,
+		int wblk, int hblk, int flags, int luma, int final_clamp, void *stream);
+
+/* final +-1023 clamp alone (reference :2668-2689) */
+int qs_hip_clamp_plane(int16_t *d_coef, int wblk, int hblk, void *stream);
+/* dequantise only (reference :2551-2566) */
+int qs_hip_dequant_plane(const void *d_consts, int16_t *d_coef, int wblk, int hblk, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,45 @@
+// qs_device.h -- shared host/device definitions for the gfx950 kernels.
+//
+// Data layout in HBM (per image component):
+//   coef   int16 [hblk][wblk][64]   JPEG blocks, natural (row-major) order --
+//                                   the packing of libjpeg's JBLOCKROWs.
+//   plane  uint8, pitch bytes/row, (hblk*8 + 2) rows.  Pixel (x, y) lives at
+//          plane[(y + 1) * pitch + QS_APRON_X + x]; x = -1, x = w, y = -1 and
+//          y = h form a clamp-to-edge apron (reference quantsmooth.h:2612-2620
+//          replicates borders into its scratch image; we let the IDCT kernel
+//          write the apron directly).  QS_APRON_X = 16 keeps every block row
+//          16-byte aligned.
+//   consts QsConsts, one per component (quant derived values + weight tables).
+#pragma once
+#include <stdint.h>
+
+#define QS_APRON_X 16
+#define QS_TAB_MAX 272 /* floats per coefficient with DIAGONALS, 160 without */
+
+// algorithm flags, numerically identical to reference libjpegqs.h:16-23
+enum {
+  QS_DIAGONALS = 1, QS_JOINT_YUV = 2, QS_UPSAMPLE_UV = 4, QS_LOW_QUALITY = 8,
+  QS_NO_REBALANCE = 16, QS_NO_REBALANCE_UV = 32, QS_TRANSCODE = 64
+};
+
+// Per-component constants, built on the host (qs_host.cpp) and read through
+// the scalar cache: every lane of a wave works on the same coefficient index,
+// so all of this is wave-uniform.
+struct QsConsts {
+  // indexed by zigzag position k (the order the recovery loop walks, 63..1)
+  int32_t nat[64];     // natural index of zigzag position k
+  int32_t q[64];       // effective quantiser (0 -> 1), reference :2506-2511
+  int32_t qraw[64];    // quantiser as stored in the file (natural index!)
+  int32_t x1[64];      // reciprocal (as signed 16-bit), reference :2514-2539
+  int32_t x2[64];      // shift term (as signed 16-bit)
+  float   range[64];   // (float)(2 * q)
+  // natural-index copies for the rebalance pass (walks k = 1..63 natural)
+  int32_t qn[64], x1n[64], x2n[64];
+  int32_t tab_size;    // 160 or 272
+  int32_t pad[15];
+  float   tab[64 * QS_TAB_MAX]; // weight tables, row k = zigzag position
+};
+
+static inline int qs_plane_pitch(int wblk) {
+  return ((wblk * 8 + QS_APRON_X + 1) + 63) & ~63;
+}

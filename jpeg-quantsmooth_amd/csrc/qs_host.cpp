@@ -1,0 +1,329 @@
+// qs_host.cpp -- host side of the flat C ABI (include/jpegqs_hip.h).
+//
+// Plane layer: thin argument checking + kernel launches.
+// Job layer  : the host-side semantics of the reference's plane driver
+//              (reference quantsmooth.h:2404-2878): validation, early-outs,
+//              iteration loop with progress/cancel between launches, final
+//              clamp, quant tables := 1 -- with the per-plane passes running
+//              as gfx950 kernels.  No CPU compute fallback exists.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (the weight tables
+// are float and must be bit-identical to the reference's, so no contraction
+// on the host side either).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <new>
+
+#include "../../include/jpegqs_hip.h"
+#include "qs_device.h"
+#include "qs_launch.h"
+
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+  return fail(e_ == hipErrorOutOfMemory ? QS_HIP_ENOMEM : QS_HIP_ENODEV, \
+              "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+extern "C" const char* qs_hip_last_error(void) { return g_err; }
+
+extern "C" int qs_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+extern "C" size_t qs_hip_consts_bytes(void) { return sizeof(QsConsts); }
+extern "C" size_t qs_hip_plane_pitch(int wblk) { return (size_t)qs_plane_pitch(wblk); }
+extern "C" size_t qs_hip_plane_bytes(int wblk, int hblk) {
+  return (size_t)qs_plane_pitch(wblk) * ((size_t)hblk * 8 + 2) + 64;
+}
+extern "C" size_t qs_hip_plane_row_offset(int wblk, int y) {
+  return (size_t)qs_plane_pitch(wblk) * (size_t)(y + 1);
+}
+extern "C" void qs_hip_free(void* p) { free(p); }
+
+// ---------------------------------------------------------------------------
+// constants
+
+// zigzag position -> natural index (ITU T.81 Figure 5; reference idct.h:24-33)
+static const unsigned char kZigzag[64] = {
+  0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5,
+  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+  58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63
+};
+
+// 8-point float LL&M inverse DCT; operation order is the reference's
+// (reference idct.h:568-591) because the weight tables must match bit for bit.
+static void idct8f(const float* in, int is, float* out, int os, bool scale) {
+  float z1, z2, z3, z4, z5, t0, t1, t2, t3, t4, t5, t6, t7;
+  z2 = in[2 * is]; z3 = in[6 * is];
+  z1 = (z2 + z3) * 0.541196100f;
+  t2 = z1 - z3 * 1.847759065f;
+  t3 = z1 + z2 * 0.765366865f;
+  z2 = in[0]; z3 = in[4 * is];
+  t0 = z2 + z3; t1 = z2 - z3;
+  t4 = t0 + t3; t7 = t0 - t3; t5 = t1 + t2; t6 = t1 - t2;
+  t0 = in[7 * is]; t1 = in[5 * is]; t2 = in[3 * is]; t3 = in[is];
+  z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; z4 = t1 + t3;
+  z5 = (z3 + z4) * 1.175875602f;
+  t0 = t0 * 0.298631336f; t1 = t1 * 2.053119869f;
+  t2 = t2 * 3.072711026f; t3 = t3 * 1.501321110f;
+  z1 = z1 * 0.899976223f; z2 = z2 * 2.562915447f;
+  z3 = z3 * 1.961570560f; z4 = z4 * 0.390180644f;
+  z3 = z3 - z5; t0 = t0 - (z1 + z3); t2 = t2 - (z2 + z3);
+  z4 = z4 - z5; t1 = t1 - (z2 + z4); t3 = t3 - (z1 + z4);
+  float r[8] = { t4 + t3, t5 + t2, t6 + t1, t7 + t0, t7 - t0, t6 - t1, t5 - t2, t4 - t3 };
+  for (int j = 0; j < 8; ++j) out[j * os] = scale ? r[j] * 0.125f : r[j];
+}
+
+static void impulse_response(int i, float T[64]) {
+  float in[64], ws[64];
+  memset(in, 0, sizeof(in)); in[i] = 1.0f;
+  for (int x = 0; x < 8; ++x) idct8f(in + x, 8, ws + x, 8, false);       // columns
+  for (int y = 0; y < 8; ++y) idct8f(ws + y * 8, 1, T + y * 8, 1, true); // rows
+}
+
+extern "C" int qs_hip_consts_build(void* host_out, const uint16_t quant[64], int flags) {
+  if (!host_out || !quant) return fail(QS_HIP_EINVAL, "qs_hip_consts_build: null argument");
+  QsConsts* c = static_cast<QsConsts*>(host_out);
+  memset(c, 0, sizeof(*c));
+  const bool diag = (flags & QS_DIAGONALS) != 0;
+  const int ts = diag ? 272 : 160;
+  const float b = diag ? 4.0f : 2.0f;
+  c->tab_size = ts;
+  int qn[64], x1n[64], x2n[64];
+  for (int i = 0; i < 64; ++i) {           // reference :2506-2539
+    unsigned q = quant[i] ? quant[i] : 1u, n = 0, t = q;
+    while (t > 1) { t >>= 1; ++n; }
+    unsigned x1 = ((0x10000u << n) + q - 1) / q;
+    if (n) x1 |= x1 >> 16;
+    int x2 = -0x8000 >> n;
+    qn[i] = (int)q; x1n[i] = (int16_t)(uint16_t)x1; x2n[i] = (int16_t)(uint16_t)x2;
+    c->qraw[i] = quant[i];
+    c->qn[i] = qn[i]; c->x1n[i] = x1n[i]; c->x2n[i] = x2n[i];
+  }
+  for (int k = 0; k < 64; ++k) {
+    const int i = kZigzag[k];
+    c->nat[k] = i; c->q[k] = qn[i]; c->x1[k] = x1n[i]; c->x2[k] = x2n[i];
+    c->range[k] = (float)(qn[i] * 2);
+    float T[64], *w = c->tab + (size_t)k * ts;   // reference :251-301, layout in SURVEY A.4
+    impulse_response(i, T);
+    for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) {
+      const int p = y * 8 + x;
+      w[p] = x < 7 ? T[p] - T[p + 1] : 0.0f;
+      w[96 + p] = y < 7 ? T[p] - T[p + 8] : 0.0f;
+    }
+    for (int x = 0; x < 8; ++x) {
+      w[64 + x] = T[x] * b; w[72 + x] = T[56 + x] * b;
+      w[80 + x] = T[8 * x] * b; w[88 + x] = T[8 * x + 7] * b;
+    }
+    if (diag)
+      for (int y = 0; y < 7; ++y) for (int x = 0; x < 8; ++x) {
+        const int p = y * 8 + x;
+        w[160 + 16 * y + x] = x < 7 ? T[p] - T[p + 9] : 0.0f;
+        w[168 + 16 * y + x] = x < 7 ? T[p + 1] - T[p + 8] : 0.0f;
+      }
+  }
+  return QS_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// plane layer
+
+static int check_plane_args(const void* a, const void* b, int wblk, int hblk, const char* who) {
+  if (!a || !b) return fail(QS_HIP_EINVAL, "%s: null device pointer", who);
+  if (wblk <= 0 || hblk <= 0 || (long long)wblk * hblk > (1ll << 28))
+    return fail(QS_HIP_EINVAL, "%s: bad plane size %dx%d blocks", who, wblk, hblk);
+  return 0;
+}
+
+static int launch_status(const char* who) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QS_HIP_ENODEV, "%s: launch failed: %s", who, hipGetErrorString(e));
+  return QS_HIP_OK;
+}
+
+extern "C" int qs_hip_idct_plane(const void* d_consts, int16_t* d_coef, uint8_t* d_plane,
+                                 int wblk, int hblk, int first, int rep_top, int rep_bot,
+                                 int32_t* d_status, void* stream) {
+  if (int r = check_plane_args(d_coef, d_plane, wblk, hblk, "qs_hip_idct_plane")) return r;
+  if (!d_consts || (first && !d_status)) return fail(QS_HIP_EINVAL, "qs_hip_idct_plane: null consts/status");
+  qs_launch_idct_plane(static_cast<const QsConsts*>(d_consts), d_coef, d_plane, wblk, hblk,
+                       first, rep_top, rep_bot, d_status, static_cast<hipStream_t>(stream));
+  return launch_status("qs_hip_idct_plane");
+}
+
+extern "C" int qs_hip_smooth_plane(const void* d_consts, int16_t* d_coef, const uint8_t* d_plane,
+                                   int wblk, int hblk, int flags, int luma, int final_clamp, void* stream) {
+  if (int r = check_plane_args(d_coef, d_plane, wblk, hblk, "qs_hip_smooth_plane")) return r;
+  if (!d_consts) return fail(QS_HIP_EINVAL, "qs_hip_smooth_plane: null consts");
+  if (flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV | QS_LOW_QUALITY))
+    return fail(QS_HIP_ENOTSUP, "qs_hip_smooth_plane: flags 0x%x need the joint/low-quality kernels", flags);
+  int rebalance = !(flags & QS_NO_REBALANCE) && (luma || !(flags & QS_NO_REBALANCE_UV)); // reference :1567-1568
+  qs_launch_smooth_plane(static_cast<const QsConsts*>(d_consts), d_coef, d_plane, wblk, hblk,
+                         (flags & QS_DIAGONALS) != 0, rebalance, final_clamp, static_cast<hipStream_t>(stream));
+  return launch_status("qs_hip_smooth_plane");
+}
+
+extern "C" int qs_hip_clamp_plane(int16_t* d_coef, int wblk, int hblk, void* stream) {
+  if (int r = check_plane_args(d_coef, d_coef, wblk, hblk, "qs_hip_clamp_plane")) return r;
+  qs_launch_clamp(d_coef, (size_t)wblk * hblk, static_cast<hipStream_t>(stream));
+  return launch_status("qs_hip_clamp_plane");
+}
+
+extern "C" int qs_hip_dequant_plane(const void* d_consts, int16_t* d_coef, int wblk, int hblk, void* stream) {
+  if (int r = check_plane_args(d_coef, d_consts, wblk, hblk, "qs_hip_dequant_plane")) return r;
+  qs_launch_dequant(static_cast<const QsConsts*>(d_consts), d_coef, (size_t)wblk * hblk, static_cast<hipStream_t>(stream));
+  return launch_status("qs_hip_dequant_plane");
+}
+
+// ---------------------------------------------------------------------------
+// job layer
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n); }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct Stream {
+  hipStream_t s = nullptr;
+  ~Stream() { if (s) (void)hipStreamDestroy(s); }
+};
+
+}  // namespace
+
+extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int progprec,
+                                     qs_hip_progress_fn progress, void* userdata) {
+  if (!job || job->ncomp < 1 || job->ncomp > QS_HIP_MAXC)
+    return fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: bad job");
+  for (int ci = 0; ci < job->ncomp; ++ci)
+    if (!job->coef[ci] || job->wblk[ci] <= 0 || job->hblk[ci] <= 0)
+      return fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: component %d has no data", ci);
+
+  job->up_wblk = job->up_hblk = 0; job->coef_up[0] = job->coef_up[1] = nullptr;
+  job->out_hsamp0 = job->hsamp[0]; job->out_vsamp0 = job->vsamp[0];
+
+  int need_lowres = 0, stop = 0;
+  if ((flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV)) && job->colorspace == 3 && job->ncomp >= 3 &&
+      job->hsamp[1] == 1 && job->vsamp[1] == 1 && job->hsamp[2] == 1 && job->vsamp[2] == 1)
+    need_lowres = 1;                                     // reference :2447-2453
+  if (niter < 0) niter = 0;
+  if (niter > 100) niter = 100;                          // reference :2455-2456
+  if (niter <= 0 && !((flags & QS_UPSAMPLE_UV) && need_lowres)) return 0;  // reference :2458
+
+  if (flags & QS_LOW_QUALITY)
+    return fail(QS_HIP_ENOTSUP, "LOW_QUALITY (quality 0-2) is not implemented on the GPU yet");
+  if (need_lowres)
+    return fail(QS_HIP_ENOTSUP, "JOINT_YUV / UPSAMPLE_UV on YCbCr are not implemented on the GPU yet");
+
+  if (qs_hip_device_count() <= 0)
+    return fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+
+  Stream st;
+  HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+
+  int prog_next = 0, prog_max = 0, prog_thr = 0;
+  if (progress) {                                        // reference :2474-2482
+    for (int ci = 0; ci < job->ncomp; ++ci) prog_max += job->hblk[ci] * job->vsamp[ci] * niter;
+    if (progprec == 0) progprec = 20;
+    if (progprec < 0) progprec = prog_max;
+    prog_thr = (int)((unsigned)(prog_max + progprec - 1) / (unsigned)progprec);
+  }
+
+  QsConsts* hc = new (std::nothrow) QsConsts;
+  if (!hc) return fail(QS_HIP_ENOMEM, "out of host memory");
+  struct HcFree { QsConsts* p; ~HcFree() { delete p; } } hc_free{hc};
+
+  for (int ci = 0; ci < job->ncomp; ++ci) {
+    const int wb = job->wblk[ci], hb = job->hblk[ci];
+    const size_t nblk = (size_t)wb * hb, cbytes = nblk * 64 * sizeof(int16_t);
+    int iters = niter, extra = 0;
+    int prog_cur = prog_next;
+    const int prog_inc = job->vsamp[ci];
+    const int luma = !ci || job->colorspace != 3;        // reference :2639
+    prog_next += hb * prog_inc * niter;
+    if (!job->has_quant[ci]) continue;                   // reference :2493
+
+    int acc = 0;
+    for (int i = 0; i < 64; ++i) acc |= job->quant[ci][i];
+    if (acc <= 1) iters = 0;                             // reference :2501
+    if (acc >= 0x800) stop = 1;                          // reference :2504
+    if (iters + extra == 0) continue;                    // reference :2542
+
+    DevBuf d_coef, d_plane, d_cst, d_status;
+    HIP_TRY(d_coef.alloc(cbytes));
+    HIP_TRY(d_cst.alloc(sizeof(QsConsts)));
+    HIP_TRY(d_status.alloc(sizeof(int32_t)));
+    if (int r = qs_hip_consts_build(hc, job->quant[ci], flags)) return r;
+    HIP_TRY(hipMemcpyAsync(d_cst.p, hc, sizeof(QsConsts), hipMemcpyHostToDevice, st.s));
+    HIP_TRY(hipMemcpyAsync(d_coef.p, job->coef[ci], cbytes, hipMemcpyHostToDevice, st.s));
+    HIP_TRY(hipMemsetAsync(d_status.p, 0, sizeof(int32_t), st.s));
+
+    bool have_plane = false;
+    if (!stop) {
+      // the reference falls back to dequantise-only when the plane cannot be
+      // allocated (reference :2551-2566); same here for device memory
+      hipError_t e = d_plane.alloc(qs_hip_plane_bytes(wb, hb));
+      if (e == hipSuccess) have_plane = true; else (void)hipGetLastError();
+    }
+    if (!have_plane) {
+      if (int r = qs_hip_dequant_plane(d_cst.p, d_coef.as<int16_t>(), wb, hb, st.s)) return r;
+      HIP_TRY(hipMemcpyAsync(job->coef[ci], d_coef.p, cbytes, hipMemcpyDeviceToHost, st.s));
+      HIP_TRY(hipStreamSynchronize(st.s));
+      continue;
+    }
+
+    bool clamped = false;
+    for (int it = 0; it < iters + extra; ++it) {
+      if (int r = qs_hip_idct_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), wb, hb,
+                                    it == 0, 1, 1, d_status.as<int32_t>(), st.s)) return r;
+      if (it == 0) {                                     // reference :2610
+        int32_t bad = 0;
+        HIP_TRY(hipMemcpyAsync(&bad, d_status.p, sizeof(bad), hipMemcpyDeviceToHost, st.s));
+        HIP_TRY(hipStreamSynchronize(st.s));
+        if (bad) { stop = 1; break; }
+      }
+      if (it == iters) break;                            // refresh-only pass, reference :2622
+      // the +-1023 clamp rides on the last smoothing launch unless a progress
+      // callback may still cancel the run after it (then it is a no-op anyway)
+      const int last = (it == iters - 1);
+      if (int r = qs_hip_smooth_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), wb, hb,
+                                      flags, luma, last, st.s)) return r;
+      if (last) clamped = true;
+      if (progress) {                                    // reference :2656-2664
+        int cur = prog_cur += hb * prog_inc;
+        if (cur >= prog_thr) {
+          cur = (int)((long long)progprec * cur / prog_max);
+          prog_thr = (int)(((long long)(cur + 1) * prog_max + progprec - 1) / progprec);
+          HIP_TRY(hipStreamSynchronize(st.s));           // the pass is done when we report it
+          stop = progress(userdata, cur, progprec);
+        }
+        if (stop) break;
+      }
+    }
+    if (!clamped)                                        // reference :2668-2689
+      if (int r = qs_hip_clamp_plane(d_coef.as<int16_t>(), wb, hb, st.s)) return r;
+    HIP_TRY(hipMemcpyAsync(job->coef[ci], d_coef.p, cbytes, hipMemcpyDeviceToHost, st.s));
+    HIP_TRY(hipStreamSynchronize(st.s));
+  }
+
+  for (int ci = 0; ci < job->ncomp; ++ci)                // reference :2851-2859
+    if (job->has_quant[ci]) for (int i = 0; i < 64; ++i) job->quant[ci][i] = 1;
+  return stop;
+}

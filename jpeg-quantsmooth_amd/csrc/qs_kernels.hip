@@ -1,0 +1,495 @@
+// qs_kernels.hip -- gfx950 (CDNA4, wave64) kernels for the jpeg-quantsmooth
+// coefficient-recovery path.  Written for MI355X only; build with
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+// (-ffp-contract=off is part of the numerical contract: the reference's scalar
+// path rounds every multiply and add separately, reference quantsmooth.h:1519).
+//
+// Work decomposition: ONE 8x8 BLOCK PER LANE, 64 blocks per wavefront.
+// Why not "one block per wavefront + cross-lane reductions": the reference's
+// scalar path accumulates each coefficient's 144/242 float terms strictly in
+// sequence (reference quantsmooth.h:1517-1545), and float addition does not
+// reassociate -- a DPP/LDS tree over 64 lanes cannot be bit-exact.  With a
+// block per lane every lane runs that exact chain privately; all lanes of a
+// wave work on the same coefficient index at the same time, so weights,
+// quantiser data and control flow are wave-uniform (scalar loads + uniform
+// branches) and nothing diverges.
+//
+// Per-lane state: the block's 64 pixels and 32 neighbour-edge pixels live in
+// VGPRs as exact small floats (pixel differences are then one v_sub_f32); the
+// 64 int16 coefficients live in LDS, one dword column per lane (stride 65
+// dwords => conflict-free both for the per-lane column accesses and for the
+// coalesced-load transpose).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "qs_device.h"
+
+#define QS_LDS_PITCH 65 /* dwords per coefficient-pair row, 64 lanes + 1 pad */
+
+// --------------------------------------------------------------------------
+// small helpers
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS traffic of one wave is processed in order; this only stops the
+  // compiler from moving LDS accesses across the point where lanes exchange
+  // data through LDS.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t mulc(uint32_t a, int c) {
+  // 24-bit multiply: exact low 32 bits whenever |a| < 2^23, which holds for
+  // every operand of the two IDCT passes (int16 inputs; pass-2 inputs are an
+  // int32 shifted right by 11, sums of at most four of them).
+  return (uint32_t)__mul24((int)a, c);
+}
+
+// 1-D LL&M inverse DCT butterfly, 13-bit constants, wrapping int32 arithmetic.
+// Behaviour of reference idct.h:57-89.
+__device__ __forceinline__ void idct8(uint32_t (&v)[8]) {
+  uint32_t z1, z2, z3, z4, z5, t0, t1, t2, t3, e0, e1, e2, e3;
+  z2 = v[2]; z3 = v[6];
+  z1 = mulc(z2 + z3, 4433);
+  t2 = z1 - mulc(z3, 15137);
+  t3 = z1 + mulc(z2, 6270);
+  t0 = (v[0] + v[4]) << 13;
+  t1 = (v[0] - v[4]) << 13;
+  e0 = t0 + t3; e3 = t0 - t3; e1 = t1 + t2; e2 = t1 - t2;
+  t0 = v[7]; t1 = v[5]; t2 = v[3]; t3 = v[1];
+  z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; z4 = t1 + t3;
+  z5 = mulc(z3 + z4, 9633);
+  t0 = mulc(t0, 2446);  t1 = mulc(t1, 16819);
+  t2 = mulc(t2, 25172); t3 = mulc(t3, 12299);
+  z1 = mulc(z1, 7373);  z2 = mulc(z2, 20995);
+  z3 = mulc(z3, 16069); z4 = mulc(z4, 3196);
+  z3 = z5 - z3; z4 = z5 - z4;
+  t0 += z3 - z1; t1 += z4 - z2; t2 += z3 - z2; t3 += z4 - z1;
+  v[0] = e0 + t3; v[7] = e0 - t3;
+  v[1] = e1 + t2; v[6] = e1 - t2;
+  v[2] = e2 + t1; v[5] = e2 - t1;
+  v[3] = e3 + t0; v[4] = e3 - t0;
+}
+
+// pass 1 (columns) of the 2-D IDCT on 64 register-resident values; keeps two
+// fractional bits (reference idct.h:481-503).
+__device__ __forceinline__ void idct_pass1(uint32_t (&ws)[64]) {
+#pragma unroll
+  for (int x = 0; x < 8; ++x) {
+    uint32_t col[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) col[j] = ws[j * 8 + x];
+    idct8(col);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ws[j * 8 + x] = (uint32_t)((int32_t)(col[j] + 1024u) >> 11);
+  }
+}
+
+// pass 2 for one row; folds +128 and rounding, clamps to 0..255
+// (reference idct.h:509-538).
+__device__ __forceinline__ void idct_pass2_row(uint32_t (&row)[8], int (&out)[8]) {
+  idct8(row);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int z = (int32_t)(row[j] + (257u << 17)) >> 18;
+    out[j] = min(max(z, 0), 255);
+  }
+}
+
+// --------------------------------------------------------------------------
+// Kernel A: (dequantise +) IDCT every block into the pixel plane and write the
+// clamp-to-edge apron.  One block per lane; consecutive lanes take consecutive
+// blocks of a block row so the 8-byte pixel-row stores of a wave coalesce into
+// 512-byte segments.  Reference quantsmooth.h:2589-2620 (pass A + borders).
+//   first   : iteration 0 -- multiply by the file's quantiser, flag
+//             out-of-range products (reference :2597-2603)
+//   rep_top / rep_bot : write the y = -1 / y = h apron rows by replication
+//             (false for the interior edges of a multi-GPU band, whose apron
+//             rows are halo rows received from the neighbouring band)
+__global__ void __launch_bounds__(256)
+qs_idct_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
+                     uint8_t* __restrict__ plane, int wblk, int hblk, int pitch,
+                     int first, int rep_top, int rep_bot, int* __restrict__ status) {
+  const int nblk = wblk * hblk;
+  const int blk = blockIdx.x * 256 + threadIdx.x;
+  if (blk >= nblk) return;
+  const int by = blk / wblk, bx = blk - by * wblk;
+
+  uint4* cp = reinterpret_cast<uint4*>(coef) + (size_t)blk * 8;
+  uint32_t ws[64];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    uint4 v = cp[j];
+    uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ws[j * 8 + c * 2] = (uint32_t)(int32_t)(int16_t)(d[c] & 0xffff);
+      ws[j * 8 + c * 2 + 1] = (uint32_t)((int32_t)d[c] >> 16);
+    }
+  }
+  if (first) {
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint32_t d[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        int lo = (int32_t)ws[j * 8 + c * 2] * cst->qraw[j * 8 + c * 2];
+        int hi = (int32_t)ws[j * 8 + c * 2 + 1] * cst->qraw[j * 8 + c * 2 + 1];
+        bad |= ((unsigned)(lo + 0x800) > 0xfffu) | ((unsigned)(hi + 0x800) > 0xfffu);
+        lo = (int16_t)lo; hi = (int16_t)hi;  // stored as JCOEF (reference :2599)
+        ws[j * 8 + c * 2] = (uint32_t)lo; ws[j * 8 + c * 2 + 1] = (uint32_t)hi;
+        d[c] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+      }
+      cp[j] = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+    if (bad) atomicOr(status, 1);
+  }
+
+  idct_pass1(ws);
+  uint8_t* org = plane + (size_t)(by * 8 + 1) * pitch + QS_APRON_X + bx * 8;
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    uint32_t row[8]; int o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) row[j] = ws[y * 8 + j];
+    idct_pass2_row(row, o);
+    uint2 pk;
+    pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+    pk.y = (uint32_t)o[4] | ((uint32_t)o[5] << 8) | ((uint32_t)o[6] << 16) | ((uint32_t)o[7] << 24);
+    uint8_t* rp = org + (size_t)y * pitch;
+    *reinterpret_cast<uint2*>(rp) = pk;
+    const bool top = (y == 0 && by == 0 && rep_top), bot = (y == 7 && by == hblk - 1 && rep_bot);
+    if (bx == 0) {
+      rp[-1] = (uint8_t)o[0];
+      if (top) rp[-1 - pitch] = (uint8_t)o[0];
+      if (bot) rp[-1 + pitch] = (uint8_t)o[0];
+    }
+    if (bx == wblk - 1) {
+      rp[8] = (uint8_t)o[7];
+      if (top) rp[8 - pitch] = (uint8_t)o[7];
+      if (bot) rp[8 + pitch] = (uint8_t)o[7];
+    }
+    if (top) *reinterpret_cast<uint2*>(rp - pitch) = pk;
+    if (bot) *reinterpret_cast<uint2*>(rp + pitch) = pk;
+  }
+}
+
+// --------------------------------------------------------------------------
+// Kernel B: the recovery loop.  Reference quantsmooth.h:1396-1565 (main loop),
+// :1566-1568 + :1823-1848 (rebalance), :2668-2689 (final clamp, optional).
+
+// float -> int32 the way x86-64 cvttss2si does it (the reference's
+// `int range = roundf(a2)`): NaN / out of range => INT_MIN.
+__device__ __forceinline__ int f2i_x86(float v) {
+  return (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
+}
+
+// C99 roundf: nearest, ties away from zero (exact: x - trunc(x) is exact).
+__device__ __forceinline__ float round_half_away(float x) {
+  float t = __builtin_truncf(x);
+  float fr = __builtin_fabsf(x - t);
+  return fr >= 0.5f ? t + __builtin_copysignf(1.0f, x) : t;
+}
+
+// nearest multiple of the quantiser (ties away from zero) via the reference's
+// reciprocal tables, and the interval that quantises to it.
+// reference quantsmooth.h:332-336, 1552-1557.
+__device__ __forceinline__ void interval(int c, int div, int x1, int x2, int& orig, int& lo, int& hi) {
+  int a = ((x1 * c) >> 16) + c;
+  a = (-a * x2 + 0x4000) >> 15;
+  a *= div;
+  const int d0 = (div - 1) >> 1, d1 = div >> 1;
+  orig = a;
+  hi = a + (a < 0 ? d1 : d0);
+  lo = a - (a > 0 ? d1 : d0);
+}
+
+__device__ __forceinline__ int lds_coef(const uint32_t* col, int i) {
+  const int16_t* p = reinterpret_cast<const int16_t*>(col + (i >> 1) * QS_LDS_PITCH) + (i & 1);
+  return *p;
+}
+__device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
+  int16_t* p = reinterpret_cast<int16_t*>(col + (i >> 1) * QS_LDS_PITCH) + (i & 1);
+  *p = (int16_t)v;
+}
+
+// one term of the weighted least-squares sums, reference quantsmooth.h:1519-1520
+#define QS_TERM(A, B, W) { \
+    float d_ = (A) - (B); \
+    float t_ = R - __builtin_fabsf(d_); \
+    t_ = __builtin_fmaxf(t_, 0.0f); \
+    t_ = t_ * t_; \
+    float x_ = d_ * t_; \
+    float y_ = (W) * t_; \
+    num = num + x_ * y_; \
+    den = den + y_ * y_; }
+
+#ifndef QS_PIN_DIFFS
+#define QS_PIN_DIFFS 1
+#endif
+#ifndef QS_SMOOTH_MIN_WAVES
+#define QS_SMOOTH_MIN_WAVES 2 /* waves per SIMD the register allocator must leave room for */
+#endif
+
+template <bool DIAG>
+__global__ void __launch_bounds__(256, QS_SMOOTH_MIN_WAVES)
+qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
+                       const uint8_t* __restrict__ plane, int wblk, int hblk, int pitch,
+                       int rebalance, int final_clamp) {
+  __shared__ uint32_t lds_all[4][32 * QS_LDS_PITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* lds = lds_all[wave];
+  uint32_t* col = lds + lane;
+  const int nblk = wblk * hblk;
+  const int base = (blockIdx.x * 4 + wave) * 64;
+  if (base >= nblk) return;  // wave-uniform
+  const int nvec = min(64, nblk - base) * 8;
+
+  // ---- stage the wave's 64 blocks (8 KiB contiguous): 16 B per lane per
+  // load, fully coalesced, transposed through LDS into per-lane columns.
+  uint4* gsrc = reinterpret_cast<uint4*>(coef) + (size_t)base * 8;
+  {
+    const int m0 = (lane & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = j * 64 + lane;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (idx < nvec) v = gsrc[idx];
+      uint32_t* dst = lds + m0 * QS_LDS_PITCH + (j * 8 + (lane >> 3));
+      dst[0] = v.x; dst[QS_LDS_PITCH] = v.y; dst[2 * QS_LDS_PITCH] = v.z; dst[3 * QS_LDS_PITCH] = v.w;
+    }
+  }
+
+  // ---- neighbour edge pixels from the frozen plane (reference :1396-1401)
+  const int blk = min(base + lane, nblk - 1);
+  const int by = blk / wblk, bx = blk - by * wblk;
+  const uint8_t* org = plane + (size_t)(by * 8 + 1) * pitch + QS_APRON_X + bx * 8;
+  float top[8], bot[8], lft[8], rgt[8];
+  {
+    const uint2 t = *reinterpret_cast<const uint2*>(org - pitch);
+    const uint2 b = *reinterpret_cast<const uint2*>(org + (size_t)8 * pitch);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      top[x] = (float)((t.x >> (8 * x)) & 0xff); top[x + 4] = (float)((t.y >> (8 * x)) & 0xff);
+      bot[x] = (float)((b.x >> (8 * x)) & 0xff); bot[x + 4] = (float)((b.y >> (8 * x)) & 0xff);
+    }
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      lft[y] = (float)org[(size_t)y * pitch - 1];
+      rgt[y] = (float)org[(size_t)y * pitch + 8];
+    }
+  }
+  wave_lds_sync();
+
+  constexpr int TS = DIAG ? 272 : 160;
+  float px[64];
+
+  // 14 zigzag anti-diagonals; the block's own pixels are re-derived from its
+  // current coefficients at the start of each (reference :313-322, 1407-1409;
+  // refreshing unconditionally is identical to refreshing "if stale").
+  int kfirst = 63;
+#pragma unroll 1
+  for (int g = 0; g < 14; ++g) {
+    {
+      uint32_t ws[64];
+#pragma unroll
+      for (int m = 0; m < 32; ++m) {
+        const uint32_t d = col[m * QS_LDS_PITCH];
+        ws[2 * m] = (uint32_t)(int32_t)(int16_t)(d & 0xffff);
+        ws[2 * m + 1] = (uint32_t)((int32_t)d >> 16);
+      }
+      idct_pass1(ws);
+#pragma unroll
+      for (int y = 0; y < 8; ++y) {
+        uint32_t row[8]; int o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[j] = ws[y * 8 + j];
+        idct_pass2_row(row, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) px[y * 8 + j] = (float)o[j];
+      }
+    }
+    // anti-diagonal g (walking down from k = 63) holds min(g + 1, 15 - g) coefficients
+    const int len = min(g + 1, 15 - g);
+    const int klast = max(kfirst - len + 1, 1);
+#pragma unroll 1
+    for (int k = kfirst; k >= klast; --k) {
+#if QS_PIN_DIFFS
+      // Keep the pixel differences inside the coefficient loop: without this
+      // the compiler hoists all 144/242 of them out of the k-loop (they only
+      // change per anti-diagonal) and pays for it in VGPRs / scratch spills.
+#pragma unroll
+      for (int p = 0; p < 64; ++p) asm volatile("" : "+v"(px[p]));
+#endif
+      const int i = cst->nat[k];
+      const float R = cst->range[k];
+      const float* __restrict__ w = cst->tab + k * TS;
+      float num = 0.0f, den = 0.0f;
+
+      if (i & 7) {
+#pragma unroll
+        for (int y = 0; y < 8; ++y)
+#pragma unroll
+          for (int x = 0; x < 7; ++x) QS_TERM(px[y * 8 + x], px[y * 8 + x + 1], w[y * 8 + x])
+      }
+#pragma unroll
+      for (int x = 0; x < 8; ++x) QS_TERM(px[x], top[x], w[64 + x])
+#pragma unroll
+      for (int x = 0; x < 8; ++x) QS_TERM(px[56 + x], bot[x], w[72 + x])
+#pragma unroll
+      for (int y = 0; y < 8; ++y) QS_TERM(px[y * 8], lft[y], w[80 + y])
+#pragma unroll
+      for (int y = 0; y < 8; ++y) QS_TERM(px[y * 8 + 7], rgt[y], w[88 + y])
+      if (i > 7) {
+#pragma unroll
+        for (int y = 0; y < 7; ++y)
+#pragma unroll
+          for (int x = 0; x < 8; ++x) QS_TERM(px[y * 8 + x], px[y * 8 + x + 8], w[96 + y * 8 + x])
+      }
+      if (DIAG) {
+#pragma unroll
+        for (int y = 0; y < 7; ++y)
+#pragma unroll
+          for (int x = 0; x < 7; ++x) {
+            QS_TERM(px[y * 8 + x], px[y * 8 + x + 9], w[160 + y * 16 + x])
+            QS_TERM(px[y * 8 + x + 1], px[y * 8 + x + 8], w[168 + y * 16 + x])
+          }
+      }
+
+      const int r = f2i_x86(round_half_away(num / den));
+      if (r != 0) {
+        const int c0 = lds_coef(col, i);
+        int orig, lo, hi;
+        interval(c0, cst->q[k], cst->x1[k], cst->x2[k], orig, lo, hi);
+        int v = (int)((uint32_t)c0 - (uint32_t)r);  // wraps like the x86 build
+        v = min(max(v, lo), hi);
+        lds_set_coef(col, i, v);
+      }
+    }
+    kfirst = klast - 1;
+  }
+
+  // ---- rebalance (reference :1823-1848): scale AC energy back towards the
+  // quantised original, inside each coefficient's interval.
+  if (rebalance) {
+    long long m0 = 0, m1 = 0;
+#pragma unroll 1
+    for (int n = 1; n < 64; ++n) {
+      const int c = lds_coef(col, n);
+      int orig, lo, hi;
+      interval(c, cst->qn[n], cst->x1n[n], cst->x2n[n], orig, lo, hi);
+      m0 += (long long)(c * orig);
+      m1 += (long long)(orig * orig);
+    }
+    if (m1 > m0) {
+      const int mul = (int)(((m1 << 13) + (m0 >> 1)) / m0);
+#pragma unroll 1
+      for (int n = 1; n < 64; ++n) {
+        const int c = lds_coef(col, n);
+        int orig, lo, hi;
+        interval(c, cst->qn[n], cst->x1n[n], cst->x2n[n], orig, lo, hi);
+        int v = (c * mul + 0x1000) >> 13;
+        v = min(max(v, lo), hi);
+        lds_set_coef(col, n, v);
+      }
+    }
+  }
+  wave_lds_sync();
+
+  // ---- write back, coalesced; optional final +-1023 clamp (reference :2680-2686)
+  {
+    const int m0 = (lane & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = j * 64 + lane;
+      const uint32_t* s = lds + m0 * QS_LDS_PITCH + (j * 8 + (lane >> 3));
+      uint32_t d[4] = {s[0], s[QS_LDS_PITCH], s[2 * QS_LDS_PITCH], s[3 * QS_LDS_PITCH]};
+      if (final_clamp) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          int lo = (int16_t)(d[c] & 0xffff), hi = (int32_t)d[c] >> 16;
+          lo = min(max(lo, -1023), 1023); hi = min(max(hi, -1023), 1023);
+          d[c] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+        }
+      }
+      if (idx < nvec) gsrc[idx] = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// Kernel C: stand-alone final clamp (used when the last smoothing launch did
+// not carry it: cancelled runs, refresh-only components).  8 coefs per lane.
+__global__ void __launch_bounds__(256)
+qs_clamp_kernel(int16_t* __restrict__ coef, size_t nvec) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  uint4* p = reinterpret_cast<uint4*>(coef);
+  for (; i < nvec; i += stride) {
+    uint4 v = p[i];
+    uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int lo = (int16_t)(d[c] & 0xffff), hi = (int32_t)d[c] >> 16;
+      lo = min(max(lo, -1023), 1023); hi = min(max(hi, -1023), 1023);
+      d[c] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+    }
+    p[i] = make_uint4(d[0], d[1], d[2], d[3]);
+  }
+}
+
+// Kernel D: dequantise only (reference :2551-2566, the path taken when the
+// component is not smoothed but the job goes on: coef *= quant, no clamp).
+__global__ void __launch_bounds__(256)
+qs_dequant_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef, size_t nvec) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  uint4* p = reinterpret_cast<uint4*>(coef);
+  for (; i < nvec; i += stride) {
+    uint4 v = p[i];
+    uint32_t d[4] = {v.x, v.y, v.z, v.w};
+    const int j = (int)(i & 7);  // which eighth of the block
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int lo = (int16_t)(d[c] & 0xffff), hi = (int32_t)d[c] >> 16;
+      lo *= cst->qraw[j * 8 + c * 2]; hi *= cst->qraw[j * 8 + c * 2 + 1];
+      d[c] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+    }
+    p[i] = make_uint4(d[0], d[1], d[2], d[3]);
+  }
+}
+
+// --------------------------------------------------------------------------
+// launchers (C++ linkage, used by qs_host.cpp through qs_launch.h)
+#include "qs_launch.h"
+
+void qs_launch_idct_plane(const QsConsts* cst, int16_t* coef, uint8_t* plane, int wblk, int hblk,
+                          int first, int rep_top, int rep_bot, int* status, hipStream_t s) {
+  const int nblk = wblk * hblk;
+  hipLaunchKernelGGL(qs_idct_plane_kernel, dim3((nblk + 255) / 256), dim3(256), 0, s,
+                     cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), first, rep_top, rep_bot, status);
+}
+
+void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* plane, int wblk, int hblk,
+                            int diag, int rebalance, int final_clamp, hipStream_t s) {
+  const int nblk = wblk * hblk;
+  const dim3 grid((nblk + 255) / 256), block(256);
+  if (diag)
+    hipLaunchKernelGGL(qs_smooth_plane_kernel<true>, grid, block, 0, s,
+                       cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), rebalance, final_clamp);
+  else
+    hipLaunchKernelGGL(qs_smooth_plane_kernel<false>, grid, block, 0, s,
+                       cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), rebalance, final_clamp);
+}
+
+void qs_launch_clamp(int16_t* coef, size_t nblk, hipStream_t s) {
+  const size_t nvec = nblk * 8;
+  const int grid = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+  hipLaunchKernelGGL(qs_clamp_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, coef, nvec);
+}
+
+void qs_launch_dequant(const QsConsts* cst, int16_t* coef, size_t nblk, hipStream_t s) {
+  const size_t nvec = nblk * 8;
+  const int grid = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+  hipLaunchKernelGGL(qs_dequant_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, cst, coef, nvec);
+}

@@ -1,0 +1,193 @@
+"""ctypes binding of libjpegqs_hip.so (include/jpegqs_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+MAXC = 4
+
+
+class FLAGS:
+    """JPEGQS_* algorithm flags, numerically the reference's (libjpegqs.h:14-32)."""
+    DIAGONALS = 1
+    JOINT_YUV = 2
+    UPSAMPLE_UV = 4
+    LOW_QUALITY = 8
+    NO_REBALANCE = 16
+    NO_REBALANCE_UV = 32
+    TRANSCODE = 64
+    MASK = 0x7F
+    ITER_MAX = 100
+
+
+def flags_for_quality(quality: int) -> int:
+    """the jpegqs CLI's --quality -> flags mapping (reference quantsmooth.c:380-393)."""
+    q = int(quality)
+    flags = 0
+    if q < 3:
+        flags |= FLAGS.LOW_QUALITY
+        q += 4
+    if q >= 4:
+        flags |= FLAGS.DIAGONALS
+    if q >= 5:
+        flags |= FLAGS.JOINT_YUV
+    if q >= 6:
+        flags |= FLAGS.UPSAMPLE_UV
+    return flags
+
+
+class QsHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libjpegqs_hip error {code}: {msg}")
+        self.code = code
+
+
+class Job(C.Structure):
+    _fields_ = [
+        ("ncomp", C.c_int32), ("colorspace", C.c_int32),
+        ("image_width", C.c_int32), ("image_height", C.c_int32),
+        ("wblk", C.c_int32 * MAXC), ("hblk", C.c_int32 * MAXC),
+        ("hsamp", C.c_int32 * MAXC), ("vsamp", C.c_int32 * MAXC),
+        ("has_quant", C.c_int32 * MAXC),
+        ("quant", (C.c_uint16 * 64) * MAXC),
+        ("coef", C.c_void_p * MAXC),
+        ("coef_up", C.c_void_p * 2),
+        ("up_wblk", C.c_int32), ("up_hblk", C.c_int32),
+        ("out_hsamp0", C.c_int32), ("out_vsamp0", C.c_int32),
+    ]
+
+
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+
+# every symbol include/jpegqs_hip.h declares: (restype, argtypes)
+ABI = {
+    "qs_hip_do_quantsmooth": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int, C.c_int, PROGRESS_FN, C.c_void_p]),
+    "qs_hip_free": (None, [C.c_void_p]),
+    "qs_hip_device_count": (C.c_int, []),
+    "qs_hip_last_error": (C.c_char_p, []),
+    "qs_hip_consts_bytes": (C.c_size_t, []),
+    "qs_hip_plane_pitch": (C.c_size_t, [C.c_int]),
+    "qs_hip_plane_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "qs_hip_plane_row_offset": (C.c_size_t, [C.c_int, C.c_int]),
+    "qs_hip_consts_build": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint16), C.c_int]),
+    "qs_hip_idct_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "qs_hip_smooth_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_clamp_plane": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_dequant_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+}
+
+
+def lib_path() -> Path:
+    return PKG_DIR / "libjpegqs_hip.so"
+
+
+def load_library(path: Path | None = None) -> C.CDLL:
+    """dlopen the HIP library; raises (no fallback) when it has not been built."""
+    p = Path(path) if path else lib_path()
+    if not p.exists():
+        raise FileNotFoundError(
+            f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {PKG_DIR / 'csrc'}`; there is no CPU fallback")
+    lib = C.CDLL(str(p))
+    for name, (res, args) in ABI.items():
+        f = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        f.restype = res
+        f.argtypes = args
+    return lib
+
+
+class HipQS:
+    """Thin object wrapper: job layer on numpy arrays, plane layer on device pointers."""
+
+    def __init__(self, path: Path | None = None):
+        self.lib = load_library(path)
+
+    # -- helpers ---------------------------------------------------------------
+    def _check(self, rc: int) -> int:
+        if rc < 0:
+            raise QsHipError(rc, self.lib.qs_hip_last_error().decode(errors="replace"))
+        return rc
+
+    def device_count(self) -> int:
+        return self.lib.qs_hip_device_count()
+
+    def consts_bytes(self) -> int:
+        return self.lib.qs_hip_consts_bytes()
+
+    def plane_pitch(self, wblk: int) -> int:
+        return self.lib.qs_hip_plane_pitch(wblk)
+
+    def plane_bytes(self, wblk: int, hblk: int) -> int:
+        return self.lib.qs_hip_plane_bytes(wblk, hblk)
+
+    def plane_row_offset(self, wblk: int, y: int) -> int:
+        return self.lib.qs_hip_plane_row_offset(wblk, y)
+
+    def consts_build(self, quant, flags: int) -> np.ndarray:
+        """host-side constant block (uint8 array) for one component"""
+        q = np.ascontiguousarray(quant, dtype=np.uint16)
+        out = np.zeros(self.consts_bytes(), dtype=np.uint8)
+        self._check(self.lib.qs_hip_consts_build(out.ctypes.data, q.ctypes.data_as(C.POINTER(C.c_uint16)), flags))
+        return out
+
+    # -- job layer -------------------------------------------------------------
+    def do_quantsmooth(self, coefs, quants, flags, niter, *, hsamp=None, vsamp=None,
+                       colorspace=None, image_size=None, progprec=0, progress=None, threads=None):
+        """Whole do_quantsmooth() on copies of the inputs; same calling convention
+        and result dict as the test oracles (`threads` is accepted and ignored:
+        the GPU has no use for jpegqs_control_t.threads)."""
+        n = len(coefs)
+        job = Job()
+        job.ncomp = n
+        job.colorspace = colorspace if colorspace is not None else (3 if n == 3 else 1)
+        hsamp = hsamp or [1] * n
+        vsamp = vsamp or [1] * n
+        work = []
+        for ci in range(n):
+            a = np.ascontiguousarray(coefs[ci], dtype=np.int16).copy()
+            assert a.ndim == 3 and a.shape[2] == 64
+            work.append(a)
+            job.hblk[ci], job.wblk[ci] = a.shape[0], a.shape[1]
+            job.hsamp[ci], job.vsamp[ci] = hsamp[ci], vsamp[ci]
+            job.coef[ci] = a.ctypes.data
+            if quants[ci] is not None:
+                job.has_quant[ci] = 1
+                for i in range(64):
+                    job.quant[ci][i] = int(quants[ci][i])
+        if image_size is None:
+            mh, mv = max(hsamp), max(vsamp)
+            image_size = (work[0].shape[1] * 8 * mh // hsamp[0], work[0].shape[0] * 8 * mv // vsamp[0])
+        job.image_width, job.image_height = image_size
+        cb = PROGRESS_FN(progress) if progress else C.cast(None, PROGRESS_FN)
+        ret = self._check(self.lib.qs_hip_do_quantsmooth(C.byref(job), flags, niter, progprec, cb, None))
+        up = job.up_wblk > 0
+        if up:
+            for j in range(2):
+                cnt = job.up_wblk * job.up_hblk * 64
+                buf = (C.c_int16 * cnt).from_address(job.coef_up[j])
+                work[1 + j] = np.frombuffer(buf, dtype=np.int16).reshape(job.up_hblk, job.up_wblk, 64).copy()
+                self.lib.qs_hip_free(job.coef_up[j])
+        qout = [np.array(job.quant[ci][:], dtype=np.uint16) if quants[ci] is not None else None
+                for ci in range(n)]
+        return dict(ret=ret, coefs=work, quants=qout, up=up,
+                    hsamp0=job.out_hsamp0, vsamp0=job.out_vsamp0)
+
+    # -- plane layer (device pointers as ints, stream as int or None) ----------
+    def idct_plane(self, d_consts, d_coef, d_plane, wblk, hblk, first, rep_top, rep_bot, d_status, stream=None):
+        self._check(self.lib.qs_hip_idct_plane(d_consts, d_coef, d_plane, wblk, hblk, int(first),
+                                               int(rep_top), int(rep_bot), d_status, stream))
+
+    def smooth_plane(self, d_consts, d_coef, d_plane, wblk, hblk, flags, luma=1, final_clamp=0, stream=None):
+        self._check(self.lib.qs_hip_smooth_plane(d_consts, d_coef, d_plane, wblk, hblk, flags,
+                                                 int(luma), int(final_clamp), stream))
+
+    def clamp_plane(self, d_coef, wblk, hblk, stream=None):
+        self._check(self.lib.qs_hip_clamp_plane(d_coef, wblk, hblk, stream))
+
+    def dequant_plane(self, d_consts, d_coef, wblk, hblk, stream=None):
+        self._check(self.lib.qs_hip_dequant_plane(d_consts, d_coef, wblk, hblk, stream))

@@ -1,0 +1,57 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import jpegqs_pkg  # noqa: E402
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return jpegqs_pkg.load()
+
+
+@pytest.fixture(scope="session")
+def synth(pkg):
+    return pkg.synth
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """our plain-C restatement (oracle/libqs_oracle.so); built on demand with gcc"""
+    from oracle.oracle import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    """the compiled unmodified reference (oracle/_ref); only where it was built"""
+    from oracle import oracle as om
+    if not om.have_ref("none"):
+        if not om.build_ref():
+            pytest.skip("oracle/_ref not built and /root/reference not mounted")
+    return om.Reference("none")
+
+
+@pytest.fixture(scope="session")
+def hip(pkg):
+    """the product library; never skipped -- a missing .so is a failure"""
+    return pkg.HipQS()
+
+
+@pytest.fixture(scope="session")
+def gpu(hip):
+    if hip.device_count() <= 0:
+        pytest.fail("no HIP device visible although the test is marked gpu")
+    return hip

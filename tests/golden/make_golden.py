@@ -1,0 +1,75 @@
+"""Generate the golden vectors under tests/golden/ from the COMPILED, UNMODIFIED
+reference (oracle/_ref/libqsref_none.so = `make SIMD=none` arithmetic, built by
+oracle/Makefile from /root/reference).  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+Each .npz holds the inputs (quantised coefficient planes, quant tables, job
+geometry, flags, niter) and the reference's outputs, so the vectors can be
+replayed anywhere (/root/reference is not needed to USE them).
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+import jpegqs_pkg  # noqa: E402
+from oracle.oracle import Reference, build_ref  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+
+
+def save(name, ref, coefs, quants, flags, niter, **kw):
+    res = ref.do_quantsmooth(coefs, quants, flags, niter, **kw)
+    d = dict(flags=flags, niter=niter, ncomp=len(coefs), ret=res["ret"], up=int(res["up"]),
+             hsamp=np.array(kw.get("hsamp") or [1] * len(coefs)),
+             vsamp=np.array(kw.get("vsamp") or [1] * len(coefs)),
+             colorspace=kw.get("colorspace") or (3 if len(coefs) == 3 else 1),
+             image_size=np.array(kw.get("image_size") or (coefs[0].shape[1] * 8, coefs[0].shape[0] * 8)),
+             hsamp0=res["hsamp0"], vsamp0=res["vsamp0"])
+    for ci in range(len(coefs)):
+        d[f"in{ci}"] = coefs[ci]; d[f"q{ci}"] = quants[ci]
+        d[f"out{ci}"] = res["coefs"][ci]; d[f"qout{ci}"] = res["quants"][ci]
+    np.savez_compressed(OUT / f"{name}.npz", **d)
+    print(name, "ret", res["ret"], "up", res["up"])
+
+
+def main():
+    assert build_ref(), "/root/reference must be mounted to regenerate golden vectors"
+    ref = Reference("none")
+    synth = jpegqs_pkg.load().synth
+    # BASELINE.json configs[0]: 64x64 grayscale, q=3 niter=3 -- per-iteration dumps
+    coef, quant = synth.synth_gray(64, 64, 50)
+    for n in (1, 2, 3):
+        save(f"gray64_q3_n{n}", ref, [coef], [quant], 0, n)
+    save("gray64_q4_n3", ref, [coef], [quant], 1, 3)
+    save("gray64_q0_n3", ref, [coef], [quant], 9, 3)
+    save("gray64_q3_norebalance_n2", ref, [coef], [quant], 16, 2)
+    coef, quant = synth.synth_gray(200, 120, 25)
+    save("gray200x120_q4_n3", ref, [coef], [quant], 1, 3)
+    # quant table with a zero entry and an all-ones table (iterations skipped)
+    coef, quant = synth.synth_gray(64, 64, 50)
+    qz = quant.copy(); qz[5] = 0
+    save("gray64_zeroquant_q3_n2", ref, [coef], [qz], 0, 2)
+    save("gray64_onesquant_q3_n2", ref, [coef], [np.ones(64, np.uint16)], 0, 2)
+    qb = quant.copy(); qb[63] = 0x800
+    save("gray64_bigquant_q3_n2", ref, [coef], [qb], 0, 2)
+    cb = coef.copy(); cb[3, 4, 0] = 300  # 300 * 16 = 4800 > 0x7ff -> bad_coef
+    save("gray64_badcoef_q3_n2", ref, [cb], [quant], 0, 2)
+    # colour: odd size 4:2:0 (edge replication, partial MCUs), all quality levels
+    j = synth.synth_ycc(141, 93, 2, 2, quality=35)
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(141, 93))
+    for q, fl in ((3, 0), (4, 1), (5, 3), (6, 7), (2, 15)):
+        save(f"ycc420_141x93_q{q}_n2", ref, j["coefs"], j["quants"], fl, 2, **kw)
+    j = synth.synth_ycc(72, 40, 1, 1, quality=60)
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(72, 40))
+    save("ycc444_72x40_q6_n2", ref, j["coefs"], j["quants"], 7, 2, **kw)
+    j = synth.synth_ycc(96, 64, 2, 1, quality=45)
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(96, 64))
+    save("ycc422_96x64_q6_n1", ref, j["coefs"], j["quants"], 7, 1, **kw)
+
+
+if __name__ == "__main__":
+    main()

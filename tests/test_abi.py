@@ -1,0 +1,100 @@
+"""CPU tests of the product library's boundary: it loads, exports every symbol
+include/jpegqs_hip.h declares, builds bit-exact constants on the host, keeps
+the reference's flag values and fails loudly (never falls back) without a GPU."""
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_header_symbols_all_exported(pkg, hip):
+    text = (ROOT / "include" / "jpegqs_hip.h").read_text()
+    declared = set(re.findall(r"\b(qs_hip_[a-z_0-9]+)\s*\(", text))
+    declared.discard("qs_hip_progress_fn")
+    assert declared, "no declarations parsed"
+    from jpeg_quantsmooth_amd import hipqs
+    assert declared == set(hipqs.ABI), declared ^ set(hipqs.ABI)
+    for name in declared:
+        assert getattr(hip.lib, name) is not None
+
+
+def test_flag_values_match_reference_api(pkg):
+    F = pkg.FLAGS
+    # reference libjpegqs.h:14-32
+    assert (F.DIAGONALS, F.JOINT_YUV, F.UPSAMPLE_UV, F.LOW_QUALITY) == (1, 2, 4, 8)
+    assert (F.NO_REBALANCE, F.NO_REBALANCE_UV, F.TRANSCODE, F.MASK, F.ITER_MAX) == (16, 32, 64, 0x7F, 100)
+    # reference quantsmooth.c:380-393
+    assert [pkg.flags_for_quality(q) for q in range(7)] == [9, 11, 15, 0, 1, 3, 7]
+
+
+def test_consts_tables_bit_exact(hip, oracle, synth):
+    quant = synth.quality_table(synth.STD_LUMA, 37)
+    quant[9] = 0  # zero multiplier -> treated as 1 (reference quantsmooth.h:2506-2511)
+    for flags in (0, 1):
+        blob = hip.consts_build(quant, flags)
+        ints = blob[:64 * 4 * 9].view(np.int32).reshape(9, 64)
+        nat, q, qraw, x1, x2 = ints[0], ints[1], ints[2], ints[3], ints[4]
+        rng = blob[64 * 4 * 5:64 * 4 * 6].view(np.float32)
+        ts = 272 if flags else 160
+        off = 64 * 4 * 9
+        assert blob[off:off + 4].view(np.int32)[0] == ts
+        tab = blob[off + 64:off + 64 + 64 * 272 * 4].view(np.float32)[:64 * ts].reshape(64, ts)
+        want = oracle.tables(flags)
+        eff, _, _ = oracle.quant_prep(quant)
+        for k in range(64):
+            i = int(nat[k])
+            assert np.array_equal(tab[k].view(np.uint32), want[i].view(np.uint32)), (flags, k)
+            assert q[k] == eff[i] and rng[k] == float(2 * eff[i])
+        assert np.array_equal(qraw, quant.astype(np.int32))
+        # reciprocal tables reproduce the exact-division interval
+        import ctypes as C
+        o = C.c_int(0)
+        for k in range(1, 64):
+            div = int(q[k])
+            for c in (-3000, -div, -1, 0, 1, div // 2, div, 5 * div + 1, 3071):
+                a = ((int(x1[k]) * c) >> 16) + c
+                a = ((-a * int(x2[k]) + 0x4000) >> 15) * div
+                assert a == oracle.interval(c, div)[0]
+
+
+def test_plane_geometry(hip):
+    for wblk in (1, 7, 8, 240, 1024, 2048):
+        pitch = hip.plane_pitch(wblk)
+        assert pitch % 64 == 0 and pitch >= wblk * 8 + 17
+        assert hip.plane_bytes(wblk, 3) >= pitch * (3 * 8 + 2)
+        assert hip.plane_row_offset(wblk, -1) == 0 and hip.plane_row_offset(wblk, 0) == pitch
+
+
+def test_early_outs_need_no_gpu(hip, synth):
+    """niter <= 0 without upsampling returns 0 and touches nothing
+    (reference quantsmooth.h:2455-2458) -- before any device is needed"""
+    coef, quant = synth.synth_gray(64, 64, 50)
+    res = hip.do_quantsmooth([coef], [quant], 0, 0)
+    assert res["ret"] == 0 and np.array_equal(res["coefs"][0], coef) and np.array_equal(res["quants"][0], quant)
+    res = hip.do_quantsmooth([coef], [quant], 1, -5)
+    assert res["ret"] == 0 and np.array_equal(res["coefs"][0], coef)
+
+
+def test_no_silent_cpu_fallback(pkg, hip, synth):
+    """without a device the job layer must raise, not compute on the CPU"""
+    if hip.device_count() > 0:
+        pytest.skip("a GPU is present; covered by the gpu tests")
+    coef, quant = synth.synth_gray(64, 64, 50)
+    with pytest.raises(pkg.QsHipError) as ei:
+        hip.do_quantsmooth([coef], [quant], 0, 1)
+    assert ei.value.code == -1  # QS_HIP_ENODEV
+
+
+def test_bad_arguments_rejected(pkg, hip):
+    with pytest.raises(pkg.QsHipError):
+        hip.smooth_plane(0, 0, 0, 8, 8, 0)
+    with pytest.raises(pkg.QsHipError):
+        hip.idct_plane(1, 1, 1, 0, 8, 0, 1, 1, 1)
+
+
+def test_missing_library_fails_loudly(pkg, tmp_path):
+    with pytest.raises(FileNotFoundError):
+        pkg.load_library(tmp_path / "libjpegqs_hip.so")
