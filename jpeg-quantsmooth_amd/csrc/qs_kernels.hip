@@ -90,8 +90,15 @@ __device__ __forceinline__ void idct_pass2_row(uint32_t (&row)[8], int (&out)[8]
   idct8(row);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    int z = (int32_t)(row[j] + (257u << 17)) >> 18;
-    out[j] = min(max(z, 0), 255);
+    // clamp BEFORE the shift (same result as clamping (x >> 18) to 0..255).
+    // Toolchain hazard, ROCm 7.2 / gfx950: hipcc turns "shift, clamp to
+    // 0..255, pack two bytes" into v_ashr_pk_u8_i32 and then ORs further
+    // bytes into bits 31:16 of its result as if they were zero -- they are
+    // not on MI355X (observed: corrupted pixels 6/7 of every row).  Clamping
+    // first keeps that instruction out; csrc/Makefile greps the ISA for it.
+    int z = (int32_t)(row[j] + (257u << 17));
+    z = min(max(z, 0), (256 << 18) - 1);
+    out[j] = z >> 18;
   }
 }
 
@@ -204,13 +211,17 @@ __device__ __forceinline__ void interval(int c, int div, int x1, int x2, int& or
   lo = a - (a > 0 ? d1 : d0);
 }
 
+// 16-bit views of the dword columns.  may_alias: these accesses overlap the
+// 32-bit accesses used for staging and for the IDCT refresh, and the compiler
+// must not reorder one kind across the other (it does under strict aliasing).
+typedef int16_t __attribute__((may_alias)) lds_i16;
 __device__ __forceinline__ int lds_coef(const uint32_t* col, int i) {
-  const int16_t* p = reinterpret_cast<const int16_t*>(col + (i >> 1) * QS_LDS_PITCH) + (i & 1);
+  const lds_i16* p = reinterpret_cast<const lds_i16*>(col + (i >> 1) * QS_LDS_PITCH) + (i & 1);
   return *p;
 }
 __device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
-  int16_t* p = reinterpret_cast<int16_t*>(col + (i >> 1) * QS_LDS_PITCH) + (i & 1);
-  *p = (int16_t)v;
+  lds_i16* p = reinterpret_cast<lds_i16*>(col + (i >> 1) * QS_LDS_PITCH) + (i & 1);
+  *p = (lds_i16)v;
 }
 
 // one term of the weighted least-squares sums, reference quantsmooth.h:1519-1520

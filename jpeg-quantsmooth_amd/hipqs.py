@@ -82,6 +82,28 @@ ABI = {
 }
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (SONAME libamdhip64.so.7, but requested by torch under the
+    unversioned name), so loading our library first would pull in /opt/rocm's
+    copy and torch would later load a SECOND runtime that sees no GPUs.  If a
+    torch install is present, map its copy first; our NEEDED libamdhip64.so.7
+    then resolves to it by SONAME and torch finds the same file by inode."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib_path() -> Path:
     return PKG_DIR / "libjpegqs_hip.so"
 
@@ -93,6 +115,7 @@ def load_library(path: Path | None = None) -> C.CDLL:
         raise FileNotFoundError(
             f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C {PKG_DIR / 'csrc'}`; there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(str(p))
     for name, (res, args) in ABI.items():
         f = getattr(lib, name)  # AttributeError if the ABI is incomplete
