@@ -117,7 +117,7 @@ extern "C" int qs_hip_consts_build(void* host_out, const uint16_t quant[64], int
   for (int k = 0; k < 64; ++k) {
     const int i = kZigzag[k];
     c->nat[k] = i; c->q[k] = qn[i]; c->x1[k] = x1n[i]; c->x2[k] = x2n[i];
-    c->range[k] = (float)(qn[i] * 2);
+    c->range[k] = (float)(qn[i] * 2) * 0.000244140625f;  // R * 2^-12, see QS_TERM_D
     float T[64], *w = c->tab + (size_t)k * ts;   // reference :251-301, layout in SURVEY A.4
     impulse_response(i, T);
     for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) {
@@ -135,6 +135,15 @@ extern "C" int qs_hip_consts_build(void* host_out, const uint16_t quant[64], int
         w[160 + 16 * y + x] = x < 7 ? T[p] - T[p + 9] : 0.0f;
         w[168 + 16 * y + x] = x < 7 ? T[p + 1] - T[p + 8] : 0.0f;
       }
+  }
+  // The kernel evaluates the sums in a 2^-k scaled domain (QS_TERM_D); that is
+  // exact only while no product underflows, which needs every non-zero weight
+  // to be comfortably above 2^-38.  The tables are fixed functions of `flags`,
+  // so this can only trip if the table construction itself is changed.
+  for (size_t j = 0; j < (size_t)64 * ts; ++j) {
+    const float a = c->tab[j] < 0 ? -c->tab[j] : c->tab[j];
+    if (a != 0.0f && a < 2.3283064e-10f /* 2^-32 */)
+      return fail(QS_HIP_EINVAL, "weight table entry %g too small for the scaled evaluation", (double)a);
   }
   return QS_HIP_OK;
 }

@@ -224,23 +224,40 @@ __device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
   *p = (lds_i16)v;
 }
 
-// one term of the weighted least-squares sums, reference quantsmooth.h:1519-1520
-#define QS_TERM(A, B, W) { \
-    float d_ = (A) - (B); \
-    float t_ = R - __builtin_fabsf(d_); \
-    t_ = __builtin_fmaxf(t_, 0.0f); \
-    t_ = t_ * t_; \
-    float x_ = d_ * t_; \
+// One term of the weighted least-squares sums, reference quantsmooth.h:1519-1520:
+//     t = max(R - |d|, 0); t *= t; x = d*t; y = w*t; num += x*y; den += y*y
+// evaluated in a power-of-two-scaled domain that needs one instruction less:
+// pixels are kept as p * 2^-12, so d' = d * 2^-12 and, with R' = R * 2^-12,
+//     u' = clamp01(R' - |d'|)   -- ONE v_sub_f32 with the |.| input modifier and
+//                                  the clamp output modifier; R = 2q <= 4094 < 2^12
+//                                  so the upper clamp never fires and u' = t * 2^-12
+//     t' = u'*u' = t^2 * 2^-24 (exact, t^2 < 2^24 is an integer)
+//     x' = fl(d'*t') = x * 2^-36,  y' = fl(w*t') = y * 2^-24
+//     num' = num * 2^-60, den' = den * 2^-48, num'/den' = (num/den) * 2^-12
+// Scaling by powers of two commutes with IEEE rounding as long as nothing
+// underflows; the smallest non-zero magnitudes are |x'| >= 2^-36 and
+// |y'| >= min|w| * 2^-24 with min|w| ~ 2^-29 (checked when the tables are
+// built, qs_host.cpp), so products stay above 2^-110 and sums of such terms are
+// exact multiples of 2^-149.  Every rounding therefore happens on the same
+// significand as in the reference's unscaled evaluation: bit-exact.
+#define QS_PIX_SCALE 0.000244140625f /* 2^-12 */
+#define QS_TERM_D(D, W) { \
+    float u_ = __builtin_amdgcn_fmed3f(Rs - __builtin_fabsf(D), 0.0f, 1.0f); \
+    float t_ = u_ * u_; \
+    float x_ = (D) * t_; \
     float y_ = (W) * t_; \
     num = num + x_ * y_; \
     den = den + y_ * y_; }
+#define QS_TERM(A, B, W) { float d_ = (A) - (B); QS_TERM_D(d_, W) }
 
 #ifndef QS_PIN_DIFFS
 #define QS_PIN_DIFFS 1
 #endif
 #ifndef QS_SMOOTH_MIN_WAVES
-#define QS_SMOOTH_MIN_WAVES 2 /* waves per SIMD the register allocator must leave room for */
+#define QS_SMOOTH_MIN_WAVES 4 /* waves per SIMD the register allocator must leave room for */
 #endif
+
+__device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >> (8 * n)) & 0xffu); }
 
 template <bool DIAG>
 __global__ void __launch_bounds__(256, QS_SMOOTH_MIN_WAVES)
@@ -271,29 +288,33 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
     }
   }
 
-  // ---- neighbour edge pixels from the frozen plane (reference :1396-1401)
+  // ---- neighbour edge pixels from the frozen plane (reference :1396-1401),
+  // kept packed (4 per VGPR): [0..1] row above, [2..3] row below,
+  // [4..5] column to the left, [6..7] column to the right
   const int blk = min(base + lane, nblk - 1);
   const int by = blk / wblk, bx = blk - by * wblk;
   const uint8_t* org = plane + (size_t)(by * 8 + 1) * pitch + QS_APRON_X + bx * 8;
-  float top[8], bot[8], lft[8], rgt[8];
+  uint32_t edge[8];
   {
     const uint2 t = *reinterpret_cast<const uint2*>(org - pitch);
     const uint2 b = *reinterpret_cast<const uint2*>(org + (size_t)8 * pitch);
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      top[x] = (float)((t.x >> (8 * x)) & 0xff); top[x + 4] = (float)((t.y >> (8 * x)) & 0xff);
-      bot[x] = (float)((b.x >> (8 * x)) & 0xff); bot[x + 4] = (float)((b.y >> (8 * x)) & 0xff);
-    }
+    edge[0] = t.x; edge[1] = t.y; edge[2] = b.x; edge[3] = b.y;
+    uint32_t l[8], r[8];
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
-      lft[y] = (float)org[(size_t)y * pitch - 1];
-      rgt[y] = (float)org[(size_t)y * pitch + 8];
+      l[y] = org[(ptrdiff_t)y * pitch - 1];
+      r[y] = org[(ptrdiff_t)y * pitch + 8];
     }
+    edge[4] = l[0] | (l[1] << 8) | (l[2] << 16) | (l[3] << 24);
+    edge[5] = l[4] | (l[5] << 8) | (l[6] << 16) | (l[7] << 24);
+    edge[6] = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+    edge[7] = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
   }
   wave_lds_sync();
 
   constexpr int TS = DIAG ? 272 : 160;
-  float px[64];
+  float px[64];   // own pixels * 2^-12
+  float bd[32];   // own edge pixel minus neighbour pixel, * 2^-12 (top, bottom, left, right)
 
   // 14 zigzag anti-diagonals; the block's own pixels are re-derived from its
   // current coefficients at the start of each (reference :313-322, 1407-1409;
@@ -317,7 +338,15 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
         for (int j = 0; j < 8; ++j) row[j] = ws[y * 8 + j];
         idct_pass2_row(row, o);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) px[y * 8 + j] = (float)o[j];
+        for (int j = 0; j < 8; ++j) px[y * 8 + j] = (float)o[j] * QS_PIX_SCALE;
+      }
+      // the 32 edge differences only change here, not per coefficient
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        bd[x]      = px[x]         - byte_f(edge[0 + (x >> 2)], x & 3) * QS_PIX_SCALE;
+        bd[8 + x]  = px[56 + x]    - byte_f(edge[2 + (x >> 2)], x & 3) * QS_PIX_SCALE;
+        bd[16 + x] = px[x * 8]     - byte_f(edge[4 + (x >> 2)], x & 3) * QS_PIX_SCALE;
+        bd[24 + x] = px[x * 8 + 7] - byte_f(edge[6 + (x >> 2)], x & 3) * QS_PIX_SCALE;
       }
     }
     // anti-diagonal g (walking down from k = 63) holds min(g + 1, 15 - g) coefficients
@@ -326,14 +355,15 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
 #pragma unroll 1
     for (int k = kfirst; k >= klast; --k) {
 #if QS_PIN_DIFFS
-      // Keep the pixel differences inside the coefficient loop: without this
-      // the compiler hoists all 144/242 of them out of the k-loop (they only
-      // change per anti-diagonal) and pays for it in VGPRs / scratch spills.
+      // Keep the interior pixel differences inside the coefficient loop:
+      // otherwise the compiler hoists all 112/210 of them out of the k-loop
+      // (they only change per anti-diagonal) and pays for it in VGPRs /
+      // scratch spills.
 #pragma unroll
       for (int p = 0; p < 64; ++p) asm volatile("" : "+v"(px[p]));
 #endif
       const int i = cst->nat[k];
-      const float R = cst->range[k];
+      const float Rs = cst->range[k];   // 2q * 2^-12
       const float* __restrict__ w = cst->tab + k * TS;
       float num = 0.0f, den = 0.0f;
 
@@ -344,13 +374,7 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
           for (int x = 0; x < 7; ++x) QS_TERM(px[y * 8 + x], px[y * 8 + x + 1], w[y * 8 + x])
       }
 #pragma unroll
-      for (int x = 0; x < 8; ++x) QS_TERM(px[x], top[x], w[64 + x])
-#pragma unroll
-      for (int x = 0; x < 8; ++x) QS_TERM(px[56 + x], bot[x], w[72 + x])
-#pragma unroll
-      for (int y = 0; y < 8; ++y) QS_TERM(px[y * 8], lft[y], w[80 + y])
-#pragma unroll
-      for (int y = 0; y < 8; ++y) QS_TERM(px[y * 8 + 7], rgt[y], w[88 + y])
+      for (int j = 0; j < 32; ++j) QS_TERM_D(bd[j], w[64 + j])
       if (i > 7) {
 #pragma unroll
         for (int y = 0; y < 7; ++y)
@@ -367,7 +391,8 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
           }
       }
 
-      const int r = f2i_x86(round_half_away(num / den));
+      // num'/den' = (num/den) * 2^-12: undo the scale (exact), then round
+      const int r = f2i_x86(round_half_away((num / den) * 4096.0f));
       if (r != 0) {
         const int c0 = lds_coef(col, i);
         int orig, lo, hi;

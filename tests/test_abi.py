@@ -47,7 +47,7 @@ def test_consts_tables_bit_exact(hip, oracle, synth):
         for k in range(64):
             i = int(nat[k])
             assert np.array_equal(tab[k].view(np.uint32), want[i].view(np.uint32)), (flags, k)
-            assert q[k] == eff[i] and rng[k] == float(2 * eff[i])
+            assert q[k] == eff[i] and rng[k] == float(2 * eff[i]) / 4096.0
         assert np.array_equal(qraw, quant.astype(np.int32))
         # reciprocal tables reproduce the exact-division interval
         import ctypes as C

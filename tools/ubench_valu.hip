@@ -117,6 +117,62 @@ __global__ void k_dep_add(float* out, float a) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = x0;
 }
 
+
+// fma with one inline-constant operand (2 VGPR reads)
+__global__ void k_fma_c(float* out, float a) {
+  float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+  for (int i = 0; i < ITER; ++i) {
+    asm volatile(
+      "v_fma_f32 %0, %0, 1.0, %8\n v_fma_f32 %0, %0, 1.0, %8\n"
+      "v_fma_f32 %1, %1, 1.0, %8\n v_fma_f32 %1, %1, 1.0, %8\n"
+      "v_fma_f32 %2, %2, 1.0, %8\n v_fma_f32 %2, %2, 1.0, %8\n"
+      "v_fma_f32 %3, %3, 1.0, %8\n v_fma_f32 %3, %3, 1.0, %8\n"
+      "v_fma_f32 %4, %4, 1.0, %8\n v_fma_f32 %4, %4, 1.0, %8\n"
+      "v_fma_f32 %5, %5, 1.0, %8\n v_fma_f32 %5, %5, 1.0, %8\n"
+      "v_fma_f32 %6, %6, 1.0, %8\n v_fma_f32 %6, %6, 1.0, %8\n"
+      "v_fma_f32 %7, %7, 1.0, %8\n v_fma_f32 %7, %7, 1.0, %8\n"
+      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+// v_fma_mix_f32 reading f16 halves
+__global__ void k_fma_mix(float* out, float a) {
+  float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+  for (int i = 0; i < ITER; ++i) {
+    asm volatile(
+      "v_fma_mix_f32 %0, %0, 1.0, %8 op_sel_hi:[1,0,1]\n v_fma_mix_f32 %0, %0, 1.0, %8 op_sel_hi:[1,0,1]\n"
+      "v_fma_mix_f32 %1, %1, 1.0, %8 op_sel_hi:[1,0,1]\n v_fma_mix_f32 %1, %1, 1.0, %8 op_sel_hi:[1,0,1]\n"
+      "v_fma_mix_f32 %2, %2, 1.0, %8 op_sel_hi:[1,0,1]\n v_fma_mix_f32 %2, %2, 1.0, %8 op_sel_hi:[1,0,1]\n"
+      "v_fma_mix_f32 %3, %3, 1.0, %8 op_sel_hi:[1,0,1]\n v_fma_mix_f32 %3, %3, 1.0, %8 op_sel_hi:[1,0,1]\n"
+      "v_fma_mix_f32 %4, %4, 1.0, %8 op_sel_hi:[1,0,1]\n v_fma_mix_f32 %4, %4, 1.0, %8 op_sel_hi:[1,0,1]\n"
+      "v_fma_mix_f32 %5, %5, 1.0, %8 op_sel_hi:[1,0,1]\n v_fma_mix_f32 %5, %5, 1.0, %8 op_sel_hi:[1,0,1]\n"
+      "v_fma_mix_f32 %6, %6, 1.0, %8 op_sel_hi:[1,0,1]\n v_fma_mix_f32 %6, %6, 1.0, %8 op_sel_hi:[1,0,1]\n"
+      "v_fma_mix_f32 %7, %7, 1.0, %8 op_sel_hi:[1,0,1]\n v_fma_mix_f32 %7, %7, 1.0, %8 op_sel_hi:[1,0,1]\n"
+      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+// the 9-op term of the recovery kernel, 4 independent terms, as the kernel issues it
+__global__ void k_term9(float* out, float a) {
+  float p0 = threadIdx.x * 1e-3f, p1 = p0 + 1e-3f, p2 = p0 + 2e-3f, p3 = p0 + 3e-3f, p4 = p0 + 4e-3f;
+  float num = 0, den = 0;
+  for (int i = 0; i < ITER; ++i) {
+    asm volatile(
+      "v_sub_f32 v20, %2, %3\n v_sub_f32 v21, %3, %4\n v_sub_f32 v22, %4, %5\n v_sub_f32 v23, %5, %6\n"
+      "v_sub_f32 v24, %7, |v20| clamp\n v_sub_f32 v25, %7, |v21| clamp\n v_sub_f32 v26, %7, |v22| clamp\n v_sub_f32 v27, %7, |v23| clamp\n"
+      "v_mul_f32 v24, v24, v24\n v_mul_f32 v25, v25, v25\n v_mul_f32 v26, v26, v26\n v_mul_f32 v27, v27, v27\n"
+      "v_mul_f32 v20, v20, v24\n v_mul_f32 v21, v21, v25\n v_mul_f32 v22, v22, v26\n v_mul_f32 v23, v23, v27\n"
+      "v_mul_f32 v24, %7, v24\n v_mul_f32 v25, %7, v25\n v_mul_f32 v26, %7, v26\n v_mul_f32 v27, %7, v27\n"
+      "v_mul_f32 v20, v20, v24\n v_mul_f32 v21, v21, v25\n v_mul_f32 v22, v22, v26\n v_mul_f32 v23, v23, v27\n"
+      "v_mul_f32 v24, v24, v24\n v_mul_f32 v25, v25, v25\n v_mul_f32 v26, v26, v26\n v_mul_f32 v27, v27, v27\n"
+      "v_add_f32 %0, %0, v20\n v_add_f32 %1, %1, v24\n v_add_f32 %0, %0, v21\n v_add_f32 %1, %1, v25\n"
+      "v_add_f32 %0, %0, v22\n v_add_f32 %1, %1, v26\n v_add_f32 %0, %0, v23\n v_add_f32 %1, %1, v27\n"
+      : "+v"(num), "+v"(den) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "s"(a)
+      : "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27");
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = num + den;
+}
+
 template <class K, class T>
 static void run(const char* name, K kern, T* out, T arg, double lane_ops_per_thread_iter, int pk) {
   for (int wps = 1; wps <= 8; wps *= 2) {
@@ -139,6 +195,9 @@ int main() {
   run("mul+add", k_mul_add, out, 1.0001f, 16, 1);
   run("pk_mul+pk_add", k_pk_mul_add, out, 1.0001f, 16, 2);
   run("fma", k_fma, out, 1.0001f, 16, 1);
+  run("fma_const", k_fma_c, out, 1.0001f, 16, 1);
+  run("fma_mix", k_fma_mix, out, 1.0001f, 16, 1);
+  run("term9 x4", k_term9, out, 0.5f, 36, 1);
   run("sub|abs|+max", k_sub_abs_max, out, 1.0001f, 16, 1);
   run("mul_lo_u32", k_mul_lo, (int*)out, 3, 16, 1);
   run("mul/mad_i24", k_mul_i24, (int*)out, 3, 16, 1);
