@@ -253,6 +253,29 @@ __device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
 #ifndef QS_PIN_DIFFS
 #define QS_PIN_DIFFS 1
 #endif
+// Explicit double-buffered scalar weight prefetch (QS_STEP below).  Measured on
+// MI355X: it makes 2-3 waves/SIMD as fast as 4, but at 4 waves/SIMD (the
+// default) the compiler's own s_load placement is already covered by the other
+// waves and is ~3% faster, so it is off by default and kept for the
+// lower-occupancy, more-registers variants.
+#ifndef QS_SMEM_PIPELINE
+#define QS_SMEM_PIPELINE 0
+#endif
+typedef float qs_w16 __attribute__((ext_vector_type(16)));
+// explicit scalar loads: the compiler does not know about them, so the wait is
+// tied to the buffer through a "+s" operand (uses cannot move above it)
+#define QS_SLOAD16(BUF, BYTEOFF) \
+  asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(BUF) : "s"(tabp), "s"((uint32_t)(BYTEOFF)) : "memory")
+#define QS_SWAIT(BUF) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(BUF) : : "memory")
+// One pipeline step: wait for the chunk in CUR, then immediately issue the load
+// of the following chunk into NXT.  The num/den operands pin the step between
+// the accumulations of the previous chunk and those of this one -- without
+// them the scheduler hoists/sinks the surrounding VALU work across the asm and
+// the load ends up right in front of its own wait.
+#define QS_STEP(CUR, NXT, BYTEOFF) \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %1, %4, %5" \
+               : "+s"(CUR), "=&s"(NXT), "+v"(num), "+v"(den) \
+               : "s"(tabp), "s"((uint32_t)(BYTEOFF)) : "memory")
 #ifndef QS_SMOOTH_MIN_WAVES
 #define QS_SMOOTH_MIN_WAVES 4 /* waves per SIMD the register allocator must leave room for */
 #endif
@@ -320,8 +343,17 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
   // current coefficients at the start of each (reference :313-322, 1407-1409;
   // refreshing unconditionally is identical to refreshing "if stale").
   int kfirst = 63;
+#if QS_SMEM_PIPELINE
+  const float* tabp = cst->tab;
+  qs_w16 WA, WB;
+  int i_cur = 63;                        // natural index of zigzag position 63
+  QS_SLOAD16(WA, (uint32_t)63 * (TS * 4));   // 63 & 7 != 0: the H section comes first
+#endif
 #pragma unroll 1
   for (int g = 0; g < 14; ++g) {
+#ifdef QS_ABLATE_IDCT
+    if (g == 0)
+#endif
     {
       uint32_t ws[64];
 #pragma unroll
@@ -362,6 +394,66 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
 #pragma unroll
       for (int p = 0; p < 64; ++p) asm volatile("" : "+v"(px[p]));
 #endif
+#if QS_SMEM_PIPELINE
+      // Weights stream through two 16-SGPR buffers (WA/WB): the s_load of the
+      // next 16-float chunk is issued right after the wait for the current
+      // one, so its latency hides behind ~140 VALU instructions instead of
+      // stalling the wave ~20 times per coefficient (the compiler otherwise
+      // places every scalar load a few instructions before its first use).
+      // Section lengths before any chunk are even (H 4, B 2, V 4 chunks), so a
+      // section always starts in WA; the first chunk of the next coefficient
+      // is prefetched from the last chunk of this one, across the IDCT refresh
+      // and the coefficient update.
+      const int i = i_cur;
+      const int i_nxt = cst->nat[k > 1 ? k - 1 : 1];
+      const float Rs = cst->range[k];   // 2q * 2^-12
+      const uint32_t kb = (uint32_t)k * (TS * 4);
+      const uint32_t next_first = (uint32_t)(k > 1 ? k - 1 : 1) * (TS * 4) + ((i_nxt & 7) ? 0u : 256u);
+      const uint32_t after_V = DIAG ? kb + 640u : next_first;
+      const uint32_t after_B = (i > 7) ? kb + 384u : after_V;
+      float num = 0.0f, den = 0.0f;
+
+#define QS_ROWS_H(W, Y0) { \
+        _Pragma("unroll") for (int yy = 0; yy < 2; ++yy) \
+        _Pragma("unroll") for (int x = 0; x < 7; ++x) \
+          QS_TERM(px[((Y0) + yy) * 8 + x], px[((Y0) + yy) * 8 + x + 1], W[yy * 8 + x]) }
+#define QS_ROWS_V(W, Y0, NY) { \
+        _Pragma("unroll") for (int yy = 0; yy < (NY); ++yy) \
+        _Pragma("unroll") for (int x = 0; x < 8; ++x) \
+          QS_TERM(px[((Y0) + yy) * 8 + x], px[((Y0) + yy) * 8 + x + 8], W[yy * 8 + x]) }
+#define QS_ROW_D(W, Y) { \
+        _Pragma("unroll") for (int x = 0; x < 7; ++x) { \
+          QS_TERM(px[(Y) * 8 + x], px[(Y) * 8 + x + 9], W[x]) \
+          QS_TERM(px[(Y) * 8 + x + 1], px[(Y) * 8 + x + 8], W[8 + x]) } }
+#define QS_EDGE16(W, J0) { \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) QS_TERM_D(bd[(J0) + j], W[j]) }
+
+      if (i & 7) {
+        QS_STEP(WA, WB, kb + 64u);  QS_ROWS_H(WA, 0)
+        QS_STEP(WB, WA, kb + 128u); QS_ROWS_H(WB, 2)
+        QS_STEP(WA, WB, kb + 192u); QS_ROWS_H(WA, 4)
+        QS_STEP(WB, WA, kb + 256u); QS_ROWS_H(WB, 6)
+      }
+      QS_STEP(WA, WB, kb + 320u);   QS_EDGE16(WA, 0)
+      QS_STEP(WB, WA, after_B);     QS_EDGE16(WB, 16)
+      if (i > 7) {
+        QS_STEP(WA, WB, kb + 448u); QS_ROWS_V(WA, 0, 2)
+        QS_STEP(WB, WA, kb + 512u); QS_ROWS_V(WB, 2, 2)
+        QS_STEP(WA, WB, kb + 576u); QS_ROWS_V(WA, 4, 2)
+        QS_STEP(WB, WA, after_V);   QS_ROWS_V(WB, 6, 1)
+      }
+      if (DIAG) {
+        QS_STEP(WA, WB, kb + 704u);  QS_ROW_D(WA, 0)
+        QS_STEP(WB, WA, kb + 768u);  QS_ROW_D(WB, 1)
+        QS_STEP(WA, WB, kb + 832u);  QS_ROW_D(WA, 2)
+        QS_STEP(WB, WA, kb + 896u);  QS_ROW_D(WB, 3)
+        QS_STEP(WA, WB, kb + 960u);  QS_ROW_D(WA, 4)
+        QS_STEP(WB, WA, kb + 1024u); QS_ROW_D(WB, 5)
+        QS_STEP(WA, WB, next_first); QS_ROW_D(WA, 6)
+        WA = WB;  // 7 chunks: restore the "first chunk is in WA" invariant
+      }
+      i_cur = i_nxt;
+#else
       const int i = cst->nat[k];
       const float Rs = cst->range[k];   // 2q * 2^-12
       const float* __restrict__ w = cst->tab + k * TS;
@@ -391,7 +483,12 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
           }
       }
 
+#endif
       // num'/den' = (num/den) * 2^-12: undo the scale (exact), then round
+#ifdef QS_ABLATE_UPDATE
+      if (num == 123.456f) lds_set_coef(col, i, (int)den);
+      continue;
+#endif
       const int r = f2i_x86(round_half_away((num / den) * 4096.0f));
       if (r != 0) {
         const int c0 = lds_coef(col, i);
@@ -404,6 +501,10 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
     }
     kfirst = klast - 1;
   }
+
+#if QS_SMEM_PIPELINE
+  QS_SWAIT(WA);  // drain the last (unused) prefetch before the wave moves on
+#endif
 
   // ---- rebalance (reference :1823-1848): scale AC energy back towards the
   // quantised original, inside each coefficient's interval.
