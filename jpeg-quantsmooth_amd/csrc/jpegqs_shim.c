@@ -1,0 +1,236 @@
+/*
+ * jpegqs_shim.c -- libjpeg-facing drop-in for the reference's library API
+ * (include/libjpegqs.h  <->  reference libjpegqs.h:47-56), host side in C.
+ *
+ * do_quantsmooth() here does what a maintainer of the reference would keep on
+ * the host: talk to libjpeg (virtual block arrays, quantisation tables,
+ * component geometry, logging, decode-mode re-initialisation) and hand the
+ * coefficient-recovery path itself to the GPU library through the flat C ABI
+ * (include/jpegqs_hip.h).  Behaviour mirrored from reference
+ * quantsmooth.h:2404-2905; citations below.
+ *
+ * Build: cc -shared -fPIC jpegqs_shim.c -I<libjpeg include> -L.. -ljpegqs_hip
+ *        (no libjpeg symbols are needed unless TRANSCODE_ONLY is left undefined,
+ *        in which case the four jinit_* entry points below come from libjpeg).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <time.h>
+
+#include "jpeglib.h"
+#include "../../include/libjpegqs.h"
+#include "../../include/jpegqs_hip.h"
+
+#define logfmt(...) fprintf(stderr, __VA_ARGS__)
+
+#ifndef TRANSCODE_ONLY
+/* libjpeg-internal entry points used to re-arm the decompressor after the
+ * coefficients / sampling factors changed (reference quantsmooth.h:33-61) */
+#define QS_DSTATE_SCANNING 205
+#define QS_DSTATE_RAW_OK 206
+EXTERN(void) jinit_d_main_controller JPP((j_decompress_ptr, boolean));
+EXTERN(void) jinit_inverse_dct JPP((j_decompress_ptr));
+EXTERN(void) jinit_upsampler JPP((j_decompress_ptr));
+EXTERN(void) jinit_color_deconverter JPP((j_decompress_ptr));
+#endif
+
+static double now_ms(void) {
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpegqs_control_t *opts) {
+	qs_hip_job job;
+	int ci, i, ret, flags = opts->flags;
+	int upsampled = 0;
+	double t0 = 0;
+	jpeg_component_info *comp;
+	JDIMENSION blk_y;
+
+	/* --info output, reference quantsmooth.h:2422-2445 */
+	if (flags & JPEGQS_INFO_COMP1)
+		for (ci = 0; ci < srcinfo->num_components; ci++) {
+			comp = srcinfo->comp_info + ci;
+			logfmt("component[%i] : table %i, samp %ix%i\n", ci, comp->quant_tbl_no,
+					comp->h_samp_factor, comp->v_samp_factor);
+		}
+	if (flags & JPEGQS_INFO_QUANT)
+		for (i = 0; i < NUM_QUANT_TBLS; i++) {
+			int x, y;
+			JQUANT_TBL *qtbl = srcinfo->quant_tbl_ptrs[i];
+			if (!qtbl) continue;
+			logfmt("quant[%i]:\n", i);
+			for (y = 0; y < DCTSIZE; y++) {
+				for (x = 0; x < DCTSIZE; x++) logfmt("%04x ", qtbl->quantval[y * DCTSIZE + x]);
+				logfmt("\n");
+			}
+		}
+	if (flags & JPEGQS_INFO_CPU) logfmt("SIMD type: hip/gfx950 (%d device(s))\n", qs_hip_device_count());
+	if (flags & JPEGQS_INFO_TIME) t0 = now_ms();
+
+	if (srcinfo->num_components < 1 || srcinfo->num_components > QS_HIP_MAXC) {
+		logfmt("jpegqs-hip: unsupported component count %d\n", srcinfo->num_components);
+		return 1;
+	}
+
+	/* ---- gather: one contiguous JCOEF array per component.
+	 * access_virt_barray hands out one JBLOCKROW (allocated row width may
+	 * exceed width_in_blocks; only the first width_in_blocks blocks count,
+	 * reference quantsmooth.h:2557-2560, 2591-2594). */
+	memset(&job, 0, sizeof(job));
+	job.ncomp = srcinfo->num_components;
+	job.colorspace = (int)srcinfo->jpeg_color_space;
+	job.image_width = (int)srcinfo->image_width;
+	job.image_height = (int)srcinfo->image_height;
+	for (ci = 0; ci < job.ncomp; ci++) {
+		size_t rowbytes;
+		comp = srcinfo->comp_info + ci;
+		job.wblk[ci] = (int)comp->width_in_blocks;
+		job.hblk[ci] = (int)comp->height_in_blocks;
+		job.hsamp[ci] = comp->h_samp_factor;
+		job.vsamp[ci] = comp->v_samp_factor;
+		job.has_quant[ci] = comp->quant_table != NULL;
+		if (comp->quant_table)
+			for (i = 0; i < DCTSIZE2; i++) job.quant[ci][i] = comp->quant_table->quantval[i];
+		if (comp->width_in_blocks == 0 || comp->height_in_blocks == 0) {
+			logfmt("jpegqs-hip: empty component %d\n", ci);
+			goto fail_free;
+		}
+		rowbytes = (size_t)comp->width_in_blocks * sizeof(JBLOCK);
+		job.coef[ci] = (int16_t*)malloc(rowbytes * comp->height_in_blocks);
+		if (!job.coef[ci]) { logfmt("jpegqs-hip: out of memory\n"); goto fail_free; }
+		for (blk_y = 0; blk_y < comp->height_in_blocks; blk_y++) {
+			JBLOCKARRAY buf = (*srcinfo->mem->access_virt_barray)
+					((j_common_ptr)srcinfo, coef_arrays[ci], blk_y, 1, FALSE);
+			memcpy((char*)job.coef[ci] + rowbytes * blk_y, buf[0], rowbytes);
+		}
+	}
+
+	ret = qs_hip_do_quantsmooth(&job, flags & JPEGQS_FLAGS_MASK, opts->niter, opts->progprec,
+			opts->progress, opts->userdata);
+	if (ret < 0) {
+		/* no CPU fallback by design: report and leave the image untouched */
+		logfmt("jpegqs-hip: %s\n", qs_hip_last_error());
+		goto fail_free;
+	}
+
+	/* The job layer rewrites every table it was given to all-ones unless it took
+	 * the reference's early-out (niter <= 0 and nothing to upsample, reference
+	 * :2458), which touches nothing -- then neither do we. */
+	{
+		int changed = job.up_wblk > 0;
+		for (ci = 0; ci < job.ncomp && !changed; ci++)
+			if (job.has_quant[ci])
+				for (i = 0; i < DCTSIZE2; i++)
+					if (job.quant[ci][i] != srcinfo->comp_info[ci].quant_table->quantval[i]) { changed = 1; break; }
+		if (!changed) {
+			for (ci = 0; ci < job.ncomp; ci++) free(job.coef[ci]);
+			return ret;
+		}
+	}
+
+	/* ---- scatter the processed blocks back */
+	for (ci = 0; ci < job.ncomp; ci++) {
+		size_t rowbytes;
+		comp = srcinfo->comp_info + ci;
+		rowbytes = (size_t)comp->width_in_blocks * sizeof(JBLOCK);
+		for (blk_y = 0; blk_y < comp->height_in_blocks; blk_y++) {
+			JBLOCKARRAY buf = (*srcinfo->mem->access_virt_barray)
+					((j_common_ptr)srcinfo, coef_arrays[ci], blk_y, 1, TRUE);
+			memcpy(buf[0], (char*)job.coef[ci] + rowbytes * blk_y, rowbytes);
+		}
+		free(job.coef[ci]); job.coef[ci] = NULL;
+	}
+
+	/* ---- UPSAMPLE_UV replaced the chroma arrays: new virtual arrays at luma
+	 * size, sampling factors 1x1 (reference :2696-2703, 2836-2849) */
+	if (job.up_wblk > 0 && job.ncomp >= 3) {
+		JDIMENSION uw = (JDIMENSION)job.up_wblk, uh = (JDIMENSION)job.up_hblk;
+		size_t rowbytes = (size_t)uw * sizeof(JBLOCK);
+		jvirt_barray_ptr up[2];
+		for (ci = 0; ci < 2; ci++)
+			up[ci] = (*srcinfo->mem->request_virt_barray)
+					((j_common_ptr)srcinfo, JPOOL_IMAGE, FALSE, uw, uh, 1);
+		(*srcinfo->mem->realize_virt_arrays)((j_common_ptr)srcinfo);
+		for (ci = 0; ci < 2; ci++) {
+			for (blk_y = 0; blk_y < uh; blk_y++) {
+				JBLOCKARRAY buf = (*srcinfo->mem->access_virt_barray)
+						((j_common_ptr)srcinfo, up[ci], blk_y, 1, TRUE);
+				memcpy(buf[0], (char*)job.coef_up[ci] + rowbytes * blk_y, rowbytes);
+			}
+			qs_hip_free(job.coef_up[ci]);
+			coef_arrays[ci + 1] = up[ci];
+			srcinfo->comp_info[ci + 1].width_in_blocks = uw;
+			srcinfo->comp_info[ci + 1].height_in_blocks = uh;
+		}
+		srcinfo->max_h_samp_factor = 1;
+		srcinfo->max_v_samp_factor = 1;
+		srcinfo->comp_info[0].h_samp_factor = 1;
+		srcinfo->comp_info[0].v_samp_factor = 1;
+		upsampled = 1;
+	}
+
+	if (!ret && (flags & JPEGQS_INFO_TIME))   /* reference :2820-2825 */
+		logfmt("quantsmooth: %.3fms\n", now_ms() - t0);
+
+	/* ---- every quantisation table becomes all-ones (reference :2851-2859) */
+	for (ci = 0; ci < NUM_QUANT_TBLS; ci++) {
+		JQUANT_TBL *qtbl = srcinfo->quant_tbl_ptrs[ci];
+		if (qtbl) for (i = 0; i < DCTSIZE2; i++) qtbl->quantval[i] = 1;
+	}
+	for (ci = 0; ci < srcinfo->num_components; ci++) {
+		JQUANT_TBL *qtbl = srcinfo->comp_info[ci].quant_table;
+		if (qtbl) for (i = 0; i < DCTSIZE2; i++) qtbl->quantval[i] = 1;
+	}
+
+#ifndef TRANSCODE_ONLY
+	/* decode mode: re-arm what depends on the tables / sampling factors so that
+	 * jpeg_read_scanlines() works (reference :2861-2876) */
+	if (!(flags & JPEGQS_TRANSCODE)) {
+		if (upsampled) {
+			jinit_color_deconverter(srcinfo);
+			jinit_upsampler(srcinfo);
+			jinit_d_main_controller(srcinfo, FALSE);
+			srcinfo->input_iMCU_row = (srcinfo->output_height + DCTSIZE - 1) / DCTSIZE;
+		}
+		jinit_inverse_dct(srcinfo);
+	}
+#else
+	(void)upsampled;
+#endif
+	return ret;
+
+fail_free:
+	for (ci = 0; ci < job.ncomp; ci++) free(job.coef[ci]);
+	return 1;
+}
+
+#ifndef TRANSCODE_ONLY
+/* reference quantsmooth.h:2880-2895 */
+boolean jpegqs_start_decompress(j_decompress_ptr cinfo, jpegqs_control_t *opts) {
+	boolean ret;
+	int use_qs = opts->niter > 0 || (opts->flags & JPEGQS_UPSAMPLE_UV);
+	if (use_qs) cinfo->buffered_image = TRUE;
+	ret = jpeg_start_decompress(cinfo);
+	if (use_qs) {
+		while (!jpeg_input_complete(cinfo)) {
+			jpeg_start_output(cinfo, cinfo->input_scan_number);
+			jpeg_finish_output(cinfo);
+		}
+		do_quantsmooth(cinfo, jpeg_read_coefficients(cinfo), opts);
+		jpeg_start_output(cinfo, cinfo->input_scan_number);
+	}
+	return ret;
+}
+
+/* reference quantsmooth.h:2897-2904 */
+boolean jpegqs_finish_decompress(j_decompress_ptr cinfo) {
+	if ((cinfo->global_state == QS_DSTATE_SCANNING || cinfo->global_state == QS_DSTATE_RAW_OK)
+			&& cinfo->buffered_image)
+		jpeg_finish_output(cinfo);
+	return jpeg_finish_decompress(cinfo);
+}
+#endif

@@ -717,3 +717,50 @@ int qso_do_quantsmooth(qso_job *job, int flags, int niter, int threads,
 		if (job->has_quant[ci]) for (i = 0; i < 64; i++) job->quant[ci][i] = 1;
 	return stop;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Band passes in the PRODUCT's plane layout (pixel (x, y) at
+ * plane[(y + 1) * pitch + apron_x + x]); used by the CPU multi-process tests to
+ * drive the band/halo logic of jpeg-quantsmooth_amd/bands.py without a GPU.
+ * rep_top / rep_bot: replicate the band's first / last pixel row into the
+ * apron row (image edge); 0 leaves the apron row alone (it is a halo row that
+ * the neighbouring band sends).                                              */
+void qso_band_idct(int16_t *coef, int wblk, int hblk, const uint16_t rawq[64], int first,
+		uint8_t *plane, int pitch, int apron_x, int rep_top, int rep_bot, int *bad) {
+	int bx, by, j, y, w = wblk * 8, h = hblk * 8, isbad = 0;
+	for (by = 0; by < hblk; by++) for (bx = 0; bx < wblk; bx++) {
+		int16_t *c = coef + ((size_t)by * wblk + bx) * 64;
+		if (first)
+			for (j = 0; j < 64; j++) {
+				int v = c[j] * rawq[j];
+				c[j] = (int16_t)v;
+				if (v < -0x800 || v > 0x7ff) isbad = 1;
+			}
+		qso_idct_islow(c, plane + (size_t)(by * 8 + 1) * pitch + apron_x + bx * 8, pitch);
+	}
+	for (y = 0; y < h; y++) {
+		uint8_t *row = plane + (size_t)(y + 1) * pitch + apron_x;
+		row[-1] = row[0]; row[w] = row[w - 1];
+	}
+	if (rep_top) memcpy(plane + apron_x - 1, plane + pitch + apron_x - 1, w + 2);
+	if (rep_bot) memcpy(plane + (size_t)(h + 1) * pitch + apron_x - 1, plane + (size_t)h * pitch + apron_x - 1, w + 2);
+	if (isbad && bad) *bad = 1;
+}
+
+void qso_band_smooth(int16_t *coef, int wblk, int hblk, const uint16_t rawq[64],
+		const uint8_t *plane, int pitch, int apron_x, int flags, int luma, int final_clamp) {
+	uint16_t q[64]; int by;
+	qso_quant_prep(rawq, q, NULL, NULL);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic)
+#endif
+	for (by = 0; by < hblk; by++) {
+		int bx, j;
+		for (bx = 0; bx < wblk; bx++) {
+			int16_t *c = coef + ((size_t)by * wblk + bx) * 64;
+			qso_block(c, q, plane + (size_t)(by * 8 + 1) * pitch + apron_x + bx * 8, NULL, pitch, flags, luma);
+			if (final_clamp)
+				for (j = 0; j < 64; j++) c[j] = c[j] > 1023 ? 1023 : c[j] < -1023 ? -1023 : c[j];
+		}
+	}
+}

@@ -63,6 +63,12 @@ void qso_block(int16_t *coef, const uint16_t eff_quant[64],
 		const uint8_t *image, const uint8_t *image2, int stride,
 		int flags, int luma);
 void qso_fdct_clamp(float *buf, int16_t *coef, const uint16_t eff_quant[64]);
+/* band passes in the product's plane layout (CPU stand-in for the kernels in
+ * the multi-process band tests) */
+void qso_band_idct(int16_t *coef, int wblk, int hblk, const uint16_t rawq[64], int first,
+		uint8_t *plane, int pitch, int apron_x, int rep_top, int rep_bot, int *bad);
+void qso_band_smooth(int16_t *coef, int wblk, int hblk, const uint16_t rawq[64],
+		const uint8_t *plane, int pitch, int apron_x, int flags, int luma, int final_clamp);
 
 #ifdef __cplusplus
 }

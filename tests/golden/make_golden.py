@@ -73,3 +73,29 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def make_cli_golden():
+    """JPEG files in -> reference CLI (scalar build) -> JPEG files out, committed
+    so the end-to-end CLI test can run where /root/reference is absent."""
+    import subprocess
+    from PIL import Image
+    synth = jpegqs_pkg.load().synth
+    cli = ROOT / "oracle" / "_ref" / "jpegqs_ref_none"
+    out = OUT / "cli"
+    out.mkdir(exist_ok=True)
+    gray = synth.synth_pixels(64, 64, seed=3)
+    Image.fromarray(gray, "L").save(out / "gray64.jpg", quality=50)
+    rgb = np.stack([synth.synth_pixels(141, 93, seed=5, variant=v) for v in range(3)], axis=-1)
+    Image.fromarray(rgb, "RGB").save(out / "rgb141x93_420.jpg", quality=35, subsampling=2)
+    Image.fromarray(rgb, "RGB").save(out / "rgb141x93_444.jpg", quality=60, subsampling=0)
+    for src in ("gray64", "rgb141x93_420", "rgb141x93_444"):
+        for q in (2, 3, 4, 5, 6):
+            dst = out / f"{src}.q{q}.ref.jpg"
+            subprocess.run([str(cli), "-q", str(q), "-n", "3", "-i", "0", "-t", "1",
+                            str(out / f"{src}.jpg"), str(dst)], check=True)
+    print(sorted(p.name for p in out.iterdir()))
+
+
+if __name__ == "__main__":
+    make_cli_golden()

@@ -1,0 +1,93 @@
+"""Band sharding: arithmetic, the N > 1 loop under gloo (world_size 2 and 3, CPU
+engine from the oracle), and N logical bands on one GPU with the real kernels."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_band_rows_cover_and_align(pkg):
+    from jpeg_quantsmooth_amd.bands import band_rows
+    for hblk in (1, 2, 7, 64, 135, 1024, 2048):
+        for world in (1, 2, 3, 4, 8):
+            for align in (1, 2):
+                rows = [band_rows(hblk, world, r, align) for r in range(world)]
+                assert rows[0][0] == 0 and rows[-1][1] == hblk
+                for (a0, a1), (b0, b1) in zip(rows[:-1], rows[1:]):
+                    assert a1 == b0 and a0 <= a1
+                    assert a1 % align == 0 or a1 == hblk
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, flags, niter, tmp):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    import torch
+    import torch.distributed as dist
+    import jpegqs_pkg
+    from oracle.oracle import Oracle
+    from band_cpu_engine import OracleBandEngine
+    pkg = jpegqs_pkg.load()
+    from jpeg_quantsmooth_amd import bands
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    coef, quant = pkg.synth.synth_gray(136, 200, 45, seed=21)     # 17 x 25 blocks
+    hblk = coef.shape[0]
+    r0, r1 = bands.band_rows(hblk, world, rank)
+    topo = bands.BandTopology(rank, world, r0, r1)
+    eng = OracleBandEngine(Oracle(), pkg.HipQS(), coef[r0:r1].copy(), quant, flags)
+    bands.run_band(eng, topo, niter, lambda: bands.exchange_halo_dist(eng, topo, dist))
+    assert not eng.bad_coef()
+    np.save(os.path.join(tmp, f"band{rank}.npy"), eng.coef)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_bands_gloo_equal_unsharded(world, flags, oracle, synth, tmp_path):
+    """world_size > 1, CPU, gloo: bands + halo exchange reproduce the unsharded result bit for bit"""
+    import torch.multiprocessing as mp
+    niter = 3
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, flags, niter, str(tmp_path)), nprocs=world, join=True)
+    coef, quant = synth.synth_gray(136, 200, 45, seed=21)
+    want = oracle.do_quantsmooth([coef], [quant], flags, niter)["coefs"][0]
+    got = np.concatenate([np.load(tmp_path / f"band{r}.npy") for r in range(world)], axis=0)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbands", [2, 5])
+def test_bands_on_one_gpu_equal_unsharded(gpu, pkg, oracle, synth, nbands):
+    """the GPU band path (rep_top/rep_bot flags + halo rows) with N logical bands on one device"""
+    import torch
+    from jpeg_quantsmooth_amd import bands
+    coef, quant = synth.synth_gray(264, 328, 50, seed=4)          # 41 x 33 blocks
+    hblk = coef.shape[0]
+    dev = torch.device("cuda:0")
+    for flags in (0, 1):
+        engines, topos = [], []
+        for r in range(nbands):
+            r0, r1 = bands.band_rows(hblk, nbands, r)
+            topos.append(bands.BandTopology(r, nbands, r0, r1))
+            engines.append(bands.HipBandEngine(gpu, torch, torch.from_numpy(coef[r0:r1].copy()).to(dev), quant, flags))
+        niter = 3
+        for it in range(niter):
+            for e, t in zip(engines, topos):
+                e.idct(it == 0, t.rep_top, t.rep_bot)
+            bands.exchange_halo_local(engines)
+            for e in engines:
+                e.smooth(it == niter - 1)
+        torch.cuda.synchronize()
+        got = np.concatenate([e.coef.cpu().numpy() for e in engines], axis=0)
+        want = oracle.do_quantsmooth([coef], [quant], flags, niter)["coefs"][0]
+        assert np.array_equal(got, want), f"flags={flags}"

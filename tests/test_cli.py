@@ -1,0 +1,82 @@
+"""The libjpeg-facing drop-in (libjpegqs.so) and the `jpegqs` CLI built on it:
+JPEG file in -> JPEG file out, compared byte for byte with what the reference's
+own CLI (scalar build) wrote for the same input (tests/golden/cli/*.ref.jpg,
+produced by tests/golden/make_golden.py)."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+PKG = ROOT / "jpeg-quantsmooth_amd"
+CLI = PKG / "jpegqs"
+GOLD = ROOT / "tests" / "golden" / "cli"
+
+
+def _need_cli():
+    if not CLI.exists():
+        pytest.fail(f"{CLI} not built (run __graft_entry__.build())")
+
+
+def test_shim_exports_reference_api(hip):
+    """libjpegqs.so exports exactly the three functions of reference libjpegqs.h:47-56"""
+    import os
+    jpeg = Path("/opt/conda/lib/libjpeg.so.9")
+    if jpeg.exists():   # the decode-mode tail needs libjpeg's jinit_* entry points
+        C.CDLL(str(jpeg), mode=os.RTLD_GLOBAL | os.RTLD_LAZY)
+    lib = C.CDLL(str(PKG / "libjpegqs.so"), mode=os.RTLD_LAZY)
+    for name in ("do_quantsmooth", "jpegqs_start_decompress", "jpegqs_finish_decompress"):
+        assert getattr(lib, name) is not None
+
+
+def test_cli_usage_and_exit_code():
+    _need_cli()
+    r = subprocess.run([str(CLI)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage:" in r.stderr and "--quality" in r.stderr
+    r = subprocess.run([str(CLI), "--bogus", "a", "b"], capture_output=True, text=True)
+    assert r.returncode == 1
+    r = subprocess.run([str(CLI), "-q", "3", "/nonexistent.jpg", "/tmp/x.jpg"], capture_output=True, text=True)
+    assert r.returncode == 1 and "can't open input file" in r.stderr
+
+
+def test_cli_without_gpu_fails_loudly_and_keeps_image(hip, tmp_path):
+    _need_cli()
+    if hip.device_count() > 0:
+        pytest.skip("GPU present")
+    out = tmp_path / "o.jpg"
+    r = subprocess.run([str(CLI), "-q", "3", "-i", "0", str(GOLD / "gray64.jpg"), str(out)],
+                       capture_output=True, text=True)
+    assert "no HIP device" in r.stderr          # the error is reported, nothing is computed on the CPU
+    assert r.returncode == 0 and out.exists()   # and the output is the (untouched) input image
+    from PIL import Image
+    import numpy as np
+    a = np.asarray(Image.open(GOLD / "gray64.jpg")); b = np.asarray(Image.open(out))
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src,quality", [("gray64", 3), ("gray64", 4), ("gray64", 5), ("gray64", 6),
+                                         ("rgb141x93_420", 3), ("rgb141x93_420", 4),
+                                         ("rgb141x93_444", 3), ("rgb141x93_444", 4)])
+def test_cli_matches_reference_cli_bytes(gpu, tmp_path, src, quality):
+    _need_cli()
+    out = tmp_path / "o.jpg"
+    for extra in ([], ["--optimize"]):
+        r = subprocess.run([str(CLI), "-q", str(quality), "-n", "3", "-i", "8", *extra,
+                            str(GOLD / f"{src}.jpg"), str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "quantsmooth:" in r.stderr       # --info 8 timing line, reference quantsmooth.h:2820-2825
+        if not extra:
+            assert out.read_bytes() == (GOLD / f"{src}.q{quality}.ref.jpg").read_bytes()
+
+
+@pytest.mark.gpu
+def test_cli_stdin_stdout_and_inplace(gpu, tmp_path):
+    _need_cli()
+    data = (GOLD / "gray64.jpg").read_bytes()
+    r = subprocess.run([str(CLI), "-q4", "-n3", "-i0", "-", "-"], input=data, capture_output=True)
+    assert r.returncode == 0 and r.stdout == (GOLD / "gray64.q4.ref.jpg").read_bytes()
+    f = tmp_path / "same.jpg"; f.write_bytes(data)
+    r = subprocess.run([str(CLI), "--quality", "4", "--niter", "3", "--info", "0", str(f), str(f)], capture_output=True)
+    assert r.returncode == 0 and f.read_bytes() == (GOLD / "gray64.q4.ref.jpg").read_bytes()
