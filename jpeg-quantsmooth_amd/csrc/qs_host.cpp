@@ -312,8 +312,11 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
       // the +-1023 clamp rides on the last smoothing launch unless a progress
       // callback may still cancel the run after it (then it is a no-op anyway)
       const int last = (it == iters - 1);
+      // JOINT_YUV / UPSAMPLE_UV only act through the low-res luma plane; without
+      // one (not YCbCr, or chroma not 1x1) they are no-ops (reference :2447-2453, 2636)
+      const int plane_flags = flags & (QS_DIAGONALS | QS_NO_REBALANCE | QS_NO_REBALANCE_UV);
       if (int r = qs_hip_smooth_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), wb, hb,
-                                      flags, luma, last, st.s)) return r;
+                                      plane_flags, luma, last, st.s)) return r;
       if (last) clamped = true;
       if (progress) {                                    // reference :2656-2664
         int cur = prog_cur += hb * prog_inc;
