@@ -38,7 +38,7 @@ enum {
 	QS_HIP_ENODEV = -1,   /* no HIP device / runtime error */
 	QS_HIP_EINVAL = -2,   /* bad argument */
 	QS_HIP_ENOMEM = -3,   /* host or device allocation failed */
-	QS_HIP_ENOTSUP = -4   /* flag combination not implemented on the GPU yet */
+	QS_HIP_ENOTSUP = -4   /* flags this entry point does not implement (use the one that does) */
 };
 
 /* ---- job layer ---------------------------------------------------------- */
@@ -104,6 +104,30 @@ int qs_hip_idct_plane(const void *d_consts, int16_t *d_coef, uint8_t *d_plane,
  * Supported here: flags & (DIAGONALS | NO_REBALANCE | NO_REBALANCE_UV). */
 int qs_hip_smooth_plane(const void *d_consts, int16_t *d_coef, const uint8_t *d_plane,
 		int wblk, int hblk, int flags, int luma, int final_clamp, void *stream);
+
+/* JOINT_YUV chroma predictor + fdct_clamp for one chroma plane (reference :577-579,
+ * 893-921, 343-347, 551-561); d_luma_lowres = luma at this plane's resolution and
+ * geometry.  rebalance/final_clamp: run them here (LOW_QUALITY chroma, which skips
+ * the recovery loop) instead of in qs_hip_smooth_plane. */
+int qs_hip_joint_plane(const void *d_consts, int16_t *d_coef, const uint8_t *d_plane,
+		const uint8_t *d_luma_lowres, int wblk, int hblk,
+		int rebalance, int final_clamp, void *stream);
+/* LOW_QUALITY pass B: range filter + fdct_clamp + rebalance (reference :924-938, 1161-1178) */
+int qs_hip_lowq_plane(const void *d_consts, int16_t *d_coef, const uint8_t *d_plane,
+		int wblk, int hblk, int rebalance, int final_clamp, void *stream);
+/* box-downsample the luma plane by ws x hs into a plane of lwblk x lhblk blocks,
+ * replicated out to its edges and apron (reference :2753-2815) */
+int qs_hip_downsample_plane(const uint8_t *d_luma, int ywblk, int yhblk, uint8_t *d_lowres,
+		int lwblk, int lhblk, int ws, int hs, void *stream);
+/* UPSAMPLE_UV: chroma plane -> full-resolution pixel buffer (pitch/size from the two
+ * helpers), guided by luma (reference :1851-2393, 2714-2730); then qs_hip_fdct_plane
+ * re-encodes it into ywblk x yhblk blocks (reference :2735-2750) */
+size_t qs_hip_upsample_pitch(int image_width, int ws);
+size_t qs_hip_upsample_bytes(int image_width, int image_height, int ws, int hs);
+int qs_hip_upsample_plane(const uint8_t *d_chroma, const uint8_t *d_luma_lowres, int cwblk,
+		const uint8_t *d_luma, int ywblk, int yhblk, uint8_t *d_pixels,
+		int image_width, int image_height, int ws, int hs, void *stream);
+int qs_hip_fdct_plane(const uint8_t *d_pixels, size_t pitch, int16_t *d_coef, int wblk, int hblk, void *stream);
 
 /* final +-1023 clamp alone (reference :2668-2689) */
 int qs_hip_clamp_plane(int16_t *d_coef, int wblk, int hblk, void *stream);

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdarg.h>
+#include <math.h>
 #include <new>
 
 #include "../../include/jpegqs_hip.h"
@@ -199,14 +200,76 @@ extern "C" int qs_hip_dequant_plane(const void* d_consts, int16_t* d_coef, int w
 }
 
 // ---------------------------------------------------------------------------
+// plane layer, cross-component / low-quality stages
+
+extern "C" int qs_hip_joint_plane(const void* d_consts, int16_t* d_coef, const uint8_t* d_plane,
+                                  const uint8_t* d_luma_lowres, int wblk, int hblk,
+                                  int rebalance, int final_clamp, void* stream) {
+  if (int r = check_plane_args(d_coef, d_plane, wblk, hblk, "qs_hip_joint_plane")) return r;
+  if (!d_consts || !d_luma_lowres) return fail(QS_HIP_EINVAL, "qs_hip_joint_plane: null consts/luma plane");
+  qs_launch_joint(static_cast<const QsConsts*>(d_consts), d_coef, d_plane, d_luma_lowres, wblk, hblk,
+                  rebalance, final_clamp, static_cast<hipStream_t>(stream));
+  return launch_status("qs_hip_joint_plane");
+}
+
+extern "C" int qs_hip_lowq_plane(const void* d_consts, int16_t* d_coef, const uint8_t* d_plane,
+                                 int wblk, int hblk, int rebalance, int final_clamp, void* stream) {
+  if (int r = check_plane_args(d_coef, d_plane, wblk, hblk, "qs_hip_lowq_plane")) return r;
+  if (!d_consts) return fail(QS_HIP_EINVAL, "qs_hip_lowq_plane: null consts");
+  const float c1 = 2.0f * sqrtf(0.5f);   // reference quantsmooth.h:926
+  qs_launch_lowq(static_cast<const QsConsts*>(d_consts), d_coef, d_plane, wblk, hblk, rebalance, final_clamp, c1,
+                 static_cast<hipStream_t>(stream));
+  return launch_status("qs_hip_lowq_plane");
+}
+
+extern "C" int qs_hip_downsample_plane(const uint8_t* d_luma, int ywblk, int yhblk, uint8_t* d_lowres,
+                                       int lwblk, int lhblk, int ws, int hs, void* stream) {
+  if (int r = check_plane_args(d_luma, d_lowres, ywblk, yhblk, "qs_hip_downsample_plane")) return r;
+  if (lwblk <= 0 || lhblk <= 0 || ws < 1 || hs < 1 || ws > 4 || hs > 4)
+    return fail(QS_HIP_EINVAL, "qs_hip_downsample_plane: bad geometry");
+  qs_launch_downsample(d_luma, ywblk, yhblk, d_lowres, lwblk, lhblk, ws, hs, static_cast<hipStream_t>(stream));
+  return launch_status("qs_hip_downsample_plane");
+}
+
+extern "C" size_t qs_hip_upsample_pitch(int image_width, int ws) {
+  const int w1 = (image_width + ws - 1) / ws;
+  return (size_t)(((w1 + 8) & -8) * ws);              // reference quantsmooth.h:2714
+}
+extern "C" size_t qs_hip_upsample_bytes(int image_width, int image_height, int ws, int hs) {
+  const int h1 = (image_height + hs - 1) / hs;
+  return qs_hip_upsample_pitch(image_width, ws) * (size_t)(((h1 + 8) & -8) * hs) + 64;   // reference :2715-2716
+}
+
+extern "C" int qs_hip_upsample_plane(const uint8_t* d_chroma, const uint8_t* d_luma_lowres, int cwblk,
+                                     const uint8_t* d_luma, int ywblk, int yhblk, uint8_t* d_pixels,
+                                     int image_width, int image_height, int ws, int hs, void* stream) {
+  if (int r = check_plane_args(d_chroma, d_luma, ywblk, yhblk, "qs_hip_upsample_plane")) return r;
+  if (!d_luma_lowres || !d_pixels || cwblk <= 0) return fail(QS_HIP_EINVAL, "qs_hip_upsample_plane: null argument");
+  const int w1 = (image_width + ws - 1) / ws, h1 = (image_height + hs - 1) / hs;
+  qs_launch_upsample(d_chroma, d_luma_lowres, cwblk, d_luma, ywblk, d_pixels, (int)qs_hip_upsample_pitch(image_width, ws),
+                     ywblk * 8, yhblk * 8, w1, h1, ws, hs, static_cast<hipStream_t>(stream));
+  return launch_status("qs_hip_upsample_plane");
+}
+
+extern "C" int qs_hip_fdct_plane(const uint8_t* d_pixels, size_t pitch, int16_t* d_coef, int wblk, int hblk, void* stream) {
+  if (int r = check_plane_args(d_pixels, d_coef, wblk, hblk, "qs_hip_fdct_plane")) return r;
+  qs_launch_fdct_plane(d_pixels, (int)pitch, d_coef, wblk, hblk, static_cast<hipStream_t>(stream));
+  return launch_status("qs_hip_fdct_plane");
+}
+
+// ---------------------------------------------------------------------------
 // job layer
 
 namespace {
 
 struct DevBuf {
   void* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { if (p) (void)hipFree(p); }
   hipError_t alloc(size_t n) { return hipMalloc(&p, n); }
+  void take(DevBuf& o) { if (p) (void)hipFree(p); p = o.p; o.p = nullptr; }
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -236,11 +299,6 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
   if (niter > 100) niter = 100;                          // reference :2455-2456
   if (niter <= 0 && !((flags & QS_UPSAMPLE_UV) && need_lowres)) return 0;  // reference :2458
 
-  if (flags & QS_LOW_QUALITY)
-    return fail(QS_HIP_ENOTSUP, "LOW_QUALITY (quality 0-2) is not implemented on the GPU yet");
-  if (need_lowres)
-    return fail(QS_HIP_ENOTSUP, "JOINT_YUV / UPSAMPLE_UV on YCbCr are not implemented on the GPU yet");
-
   if (qs_hip_device_count() <= 0)
     return fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
 
@@ -259,6 +317,12 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
   if (!hc) return fail(QS_HIP_ENOMEM, "out of host memory");
   struct HcFree { QsConsts* p; ~HcFree() { delete p; } } hc_free{hc};
 
+  // planes that outlive their component (reference image1 / image2, :2753-2815)
+  DevBuf d_yfull, d_llow;          // full-res luma plane; luma at chroma resolution
+  bool have_yfull = false, have_llow = false;
+  int16_t* up_host[2] = { nullptr, nullptr };
+  struct UpFree { int16_t** p; bool keep; ~UpFree() { if (!keep) { free(p[0]); free(p[1]); } } } up_free{up_host, false};
+
   for (int ci = 0; ci < job->ncomp; ++ci) {
     const int wb = job->wblk[ci], hb = job->hblk[ci];
     const size_t nblk = (size_t)wb * hb, cbytes = nblk * 64 * sizeof(int16_t);
@@ -268,6 +332,7 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
     const int luma = !ci || job->colorspace != 3;        // reference :2639
     prog_next += hb * prog_inc * niter;
     if (!job->has_quant[ci]) continue;                   // reference :2493
+    if (have_yfull || (!ci && need_lowres)) extra = 1;   // reference :2495
 
     int acc = 0;
     for (int i = 0; i < 64; ++i) acc |= job->quant[ci][i];
@@ -298,6 +363,10 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
       continue;
     }
 
+    const int rebalance = !(flags & QS_NO_REBALANCE) && (luma || !(flags & QS_NO_REBALANCE_UV));  // :1567-1568
+    // JOINT_YUV acts through the low-res luma plane only (reference :2636)
+    const bool joint = have_llow && (flags & QS_JOINT_YUV);
+    const int plane_flags = flags & (QS_DIAGONALS | QS_NO_REBALANCE | QS_NO_REBALANCE_UV);
     bool clamped = false;
     for (int it = 0; it < iters + extra; ++it) {
       if (int r = qs_hip_idct_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), wb, hb,
@@ -309,14 +378,23 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
         if (bad) { stop = 1; break; }
       }
       if (it == iters) break;                            // refresh-only pass, reference :2622
-      // the +-1023 clamp rides on the last smoothing launch unless a progress
-      // callback may still cancel the run after it (then it is a no-op anyway)
+      // pass B.  The +-1023 clamp rides on the last launch of the last iteration.
       const int last = (it == iters - 1);
-      // JOINT_YUV / UPSAMPLE_UV only act through the low-res luma plane; without
-      // one (not YCbCr, or chroma not 1x1) they are no-ops (reference :2447-2453, 2636)
-      const int plane_flags = flags & (QS_DIAGONALS | QS_NO_REBALANCE | QS_NO_REBALANCE_UV);
-      if (int r = qs_hip_smooth_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), wb, hb,
-                                      plane_flags, luma, last, st.s)) return r;
+      if (flags & QS_LOW_QUALITY) {                      // reference :924-938: never reaches the k-loop
+        if (joint) {
+          if (int r = qs_hip_joint_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), d_llow.as<uint8_t>(),
+                                         wb, hb, rebalance, last, st.s)) return r;
+        } else {
+          if (int r = qs_hip_lowq_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), wb, hb,
+                                        rebalance, last, st.s)) return r;
+        }
+      } else {
+        if (joint)
+          if (int r = qs_hip_joint_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), d_llow.as<uint8_t>(),
+                                         wb, hb, 0, 0, st.s)) return r;
+        if (int r = qs_hip_smooth_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), wb, hb,
+                                        plane_flags, luma, last, st.s)) return r;
+      }
       if (last) clamped = true;
       if (progress) {                                    // reference :2656-2664
         int cur = prog_cur += hb * prog_inc;
@@ -332,9 +410,46 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
     if (!clamped)                                        // reference :2668-2689
       if (int r = qs_hip_clamp_plane(d_coef.as<int16_t>(), wb, hb, st.s)) return r;
     HIP_TRY(hipMemcpyAsync(job->coef[ci], d_coef.p, cbytes, hipMemcpyDeviceToHost, st.s));
+
+    if (!stop && have_yfull) {
+      // UPSAMPLE_UV: chroma -> luma resolution, re-encoded (reference :2691-2752)
+      const int ws = job->hsamp[0], hs = job->vsamp[0];
+      const int uwb = job->wblk[0], uhb = job->hblk[0];
+      const size_t ubytes = (size_t)uwb * uhb * 64 * sizeof(int16_t);
+      DevBuf d_px, d_up;
+      HIP_TRY(d_px.alloc(qs_hip_upsample_bytes(job->image_width, job->image_height, ws, hs)));
+      HIP_TRY(d_up.alloc(ubytes));
+      up_host[ci - 1] = static_cast<int16_t*>(malloc(ubytes));
+      if (!up_host[ci - 1]) return fail(QS_HIP_ENOMEM, "out of host memory");
+      if (int r = qs_hip_upsample_plane(d_plane.as<uint8_t>(), d_llow.as<uint8_t>(), wb, d_yfull.as<uint8_t>(),
+                                        uwb, uhb, d_px.as<uint8_t>(), job->image_width, job->image_height,
+                                        ws, hs, st.s)) return r;
+      if (int r = qs_hip_fdct_plane(d_px.as<uint8_t>(), qs_hip_upsample_pitch(job->image_width, ws),
+                                    d_up.as<int16_t>(), uwb, uhb, st.s)) return r;
+      HIP_TRY(hipMemcpyAsync(up_host[ci - 1], d_up.p, ubytes, hipMemcpyDeviceToHost, st.s));
+      HIP_TRY(hipStreamSynchronize(st.s));
+    } else if (!stop && !ci && need_lowres) {
+      // keep luma for the chroma passes (reference :2753-2815)
+      const int ws = job->hsamp[0], hs = job->vsamp[0];
+      if (ws == 1 && hs == 1) {
+        d_llow.take(d_plane); have_llow = true;          // image2 = image
+      } else {
+        DevBuf d_l;
+        HIP_TRY(d_l.alloc(qs_hip_plane_bytes(job->wblk[1], job->hblk[1])));
+        if (int r = qs_hip_downsample_plane(d_plane.as<uint8_t>(), wb, hb, d_l.as<uint8_t>(),
+                                            job->wblk[1], job->hblk[1], ws, hs, st.s)) return r;
+        d_llow.take(d_l); have_llow = true;
+        if (flags & QS_UPSAMPLE_UV) { d_yfull.take(d_plane); have_yfull = true; }   // image1 = image
+      }
+    }
     HIP_TRY(hipStreamSynchronize(st.s));
   }
 
+  if (!stop && have_yfull && up_host[0] && up_host[1]) {  // reference :2836-2849
+    job->coef_up[0] = up_host[0]; job->coef_up[1] = up_host[1]; up_free.keep = true;
+    job->up_wblk = job->wblk[0]; job->up_hblk = job->hblk[0];
+    job->out_hsamp0 = job->out_vsamp0 = 1;
+  }
   for (int ci = 0; ci < job->ncomp; ++ci)                // reference :2851-2859
     if (job->has_quant[ci]) for (int i = 0; i < 64; ++i) job->quant[ci][i] = 1;
   return stop;

@@ -185,31 +185,7 @@ qs_idct_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coe
 // Kernel B: the recovery loop.  Reference quantsmooth.h:1396-1565 (main loop),
 // :1566-1568 + :1823-1848 (rebalance), :2668-2689 (final clamp, optional).
 
-// float -> int32 the way x86-64 cvttss2si does it (the reference's
-// `int range = roundf(a2)`): NaN / out of range => INT_MIN.
-__device__ __forceinline__ int f2i_x86(float v) {
-  return (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
-}
-
-// C99 roundf: nearest, ties away from zero (exact: x - trunc(x) is exact).
-__device__ __forceinline__ float round_half_away(float x) {
-  float t = __builtin_truncf(x);
-  float fr = __builtin_fabsf(x - t);
-  return fr >= 0.5f ? t + __builtin_copysignf(1.0f, x) : t;
-}
-
-// nearest multiple of the quantiser (ties away from zero) via the reference's
-// reciprocal tables, and the interval that quantises to it.
-// reference quantsmooth.h:332-336, 1552-1557.
-__device__ __forceinline__ void interval(int c, int div, int x1, int x2, int& orig, int& lo, int& hi) {
-  int a = ((x1 * c) >> 16) + c;
-  a = (-a * x2 + 0x4000) >> 15;
-  a *= div;
-  const int d0 = (div - 1) >> 1, d1 = div >> 1;
-  orig = a;
-  hi = a + (a < 0 ? d1 : d0);
-  lo = a - (a > 0 ? d1 : d0);
-}
+#include "qs_devfn.h"
 
 // 16-bit views of the dword columns.  may_alias: these accesses overlap the
 // 32-bit accesses used for staging and for the IDCT refresh, and the compiler

@@ -11,3 +11,14 @@ void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* p
                             int diag, int rebalance, int final_clamp, hipStream_t s);
 void qs_launch_clamp(int16_t* coef, size_t nblk, hipStream_t s);
 void qs_launch_dequant(const QsConsts* cst, int16_t* coef, size_t nblk, hipStream_t s);
+
+// qs_kernels_aux.hip: cross-component (JOINT_YUV / UPSAMPLE_UV) and LOW_QUALITY stages
+void qs_launch_joint(const QsConsts* cst, int16_t* coef, const uint8_t* planeC, const uint8_t* planeL,
+                     int wblk, int hblk, int do_rebalance, int final_clamp, hipStream_t s);
+void qs_launch_lowq(const QsConsts* cst, int16_t* coef, const uint8_t* plane, int wblk, int hblk,
+                    int do_rebalance, int final_clamp, float c1, hipStream_t s);
+void qs_launch_downsample(const uint8_t* Y, int ywblk, int yhblk, uint8_t* L, int lwblk, int lhblk,
+                          int ws, int hs, hipStream_t s);
+void qs_launch_upsample(const uint8_t* C, const uint8_t* L, int cwblk, const uint8_t* Y, int ywblk,
+                        uint8_t* out, int st, int ww, int hh, int w1, int h1, int ws, int hs, hipStream_t s);
+void qs_launch_fdct_plane(const uint8_t* px, int st, int16_t* coef, int wblk, int hblk, hipStream_t s);

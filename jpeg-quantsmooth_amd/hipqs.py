@@ -77,6 +77,16 @@ ABI = {
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "qs_hip_smooth_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_joint_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_lowq_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_downsample_plane": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_upsample_pitch": (C.c_size_t, [C.c_int, C.c_int]),
+    "qs_hip_upsample_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "qs_hip_upsample_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_fdct_plane": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_clamp_plane": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_dequant_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }

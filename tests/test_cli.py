@@ -56,9 +56,8 @@ def test_cli_without_gpu_fails_loudly_and_keeps_image(hip, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("src,quality", [("gray64", 3), ("gray64", 4), ("gray64", 5), ("gray64", 6),
-                                         ("rgb141x93_420", 3), ("rgb141x93_420", 4),
-                                         ("rgb141x93_444", 3), ("rgb141x93_444", 4)])
+@pytest.mark.parametrize("src", ["gray64", "rgb141x93_420", "rgb141x93_444"])
+@pytest.mark.parametrize("quality", [2, 3, 4, 5, 6])
 def test_cli_matches_reference_cli_bytes(gpu, tmp_path, src, quality):
     _need_cli()
     out = tmp_path / "o.jpg"

@@ -46,6 +46,31 @@ def test_gpu_vs_oracle_colour_independent_components(gpu, oracle, synth):
         assert_same_result(a, b, f"ycc420 flags={flags}")
 
 
+@pytest.mark.parametrize("size,samp", [((64, 64), (2, 2)), ((333, 517), (2, 2)), ((321, 100), (2, 2)),
+                                       ((129, 65), (1, 1)), ((100, 60), (2, 1)), ((90, 70), (1, 2)),
+                                       ((8, 8), (2, 2)), ((200, 64), (4, 1))])
+def test_gpu_vs_oracle_colour_all_flags(gpu, oracle, synth, size, samp):
+    """every --quality level on YCbCr: JOINT_YUV predictor, luma downsample,
+    UPSAMPLE_UV + re-FDCT, LOW_QUALITY; all chroma layouts incl. odd sizes"""
+    w, h = size
+    j = synth.synth_ycc(w, h, samp[0], samp[1], quality=40, seed=99)
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(w, h))
+    for flags in (3, 7, 5, 2, 9, 10, 11, 15, 7 | 16, 7 | 32, 4):
+        for niter in (0, 2):
+            a = gpu.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+            b = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+            assert_same_result(a, b, f"{size} {samp} flags={flags} niter={niter}")
+
+
+def test_gpu_low_quality_gray(gpu, oracle, synth):
+    for (w, h, qual) in ((64, 64, 50), (200, 120, 20), (24, 88, 92)):
+        coef, quant = synth.synth_gray(w, h, qual, seed=5)
+        for flags in (8, 9, 8 | 16):
+            a = gpu.do_quantsmooth([coef], [quant], flags, 3)
+            b = oracle.do_quantsmooth([coef], [quant], flags, 3)
+            assert_same_result(a, b, f"{w}x{h} q{qual} flags={flags}")
+
+
 def test_gpu_hostile_inputs(gpu, oracle, synth):
     """saturated / degenerate blocks: the a3 == 0 (NaN -> INT_MIN) path, huge
     ratios, zero quantisers, coefficients at the range limits"""
