@@ -370,6 +370,10 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
 #pragma unroll
       for (int p = 0; p < 64; ++p) asm volatile("" : "+v"(px[p]));
 #endif
+      // quantiser scalars for the update below: fetched here, not inside the
+      // divergent branch where their latency would be exposed every time
+      int qk = cst->q[k], x1k = cst->x1[k], x2k = cst->x2[k];
+      asm volatile("" : "+s"(qk), "+s"(x1k), "+s"(x2k));
 #if QS_SMEM_PIPELINE
       // Weights stream through two 16-SGPR buffers (WA/WB): the s_load of the
       // next 16-float chunk is issued right after the wait for the current
@@ -469,7 +473,7 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
       if (r != 0) {
         const int c0 = lds_coef(col, i);
         int orig, lo, hi;
-        interval(c0, cst->q[k], cst->x1[k], cst->x2[k], orig, lo, hi);
+        interval(c0, qk, x1k, x2k, orig, lo, hi);
         int v = (int)((uint32_t)c0 - (uint32_t)r);  // wraps like the x86 build
         v = min(max(v, lo), hi);
         lds_set_coef(col, i, v);
@@ -486,7 +490,7 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
   // quantised original, inside each coefficient's interval.
   if (rebalance) {
     long long m0 = 0, m1 = 0;
-#pragma unroll 1
+#pragma unroll 9
     for (int n = 1; n < 64; ++n) {
       const int c = lds_coef(col, n);
       int orig, lo, hi;
@@ -496,7 +500,7 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
     }
     if (m1 > m0) {
       const int mul = (int)(((m1 << 13) + (m0 >> 1)) / m0);
-#pragma unroll 1
+#pragma unroll 9
       for (int n = 1; n < 64; ++n) {
         const int c = lds_coef(col, n);
         int orig, lo, hi;

@@ -326,6 +326,9 @@ static float regress_scale(const uint8_t *A, int sa, const uint8_t *B, int sb,
 }
 
 /* ------------------------------------------------------------------------ */
+#ifdef QSO_STATS
+long long qso_stat_groups, qso_stat_refreshes; /* instrumentation for design studies */
+#endif
 /* one smoothing term; reference quantsmooth.h:1519-1520 */
 #define TERM(diff, wgt) do { \
 	float d_ = (float)(diff), w_ = (wgt), t_ = R - fabsf(d_); \
@@ -393,6 +396,9 @@ void qso_block(int16_t *coef, const uint16_t q[64],
 			int i = zz2nat[k], r;
 			const float *w = tables + (size_t)i * tsize;
 			float num = 0, den = 0, R = (float)(q[i] * 2);
+#ifdef QSO_STATS
+			if (starts_antidiagonal(k)) { qso_stat_groups++; if (stale) qso_stat_refreshes++; }
+#endif
 			if (stale && starts_antidiagonal(k)) { qso_idct_islow(coef, px, 8); stale = 0; }
 
 			if (i & 7) /* coefficient varies horizontally */

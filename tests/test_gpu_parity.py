@@ -162,3 +162,63 @@ def test_gpu_large_plane_properties(gpu, oracle, synth):
     inside = np.abs(g - deq) <= half
     clamped = np.abs(g) == 1023
     assert (inside | clamped).all()
+
+
+def test_gpu_other_colour_spaces_and_missing_tables(gpu, oracle, synth):
+    """4 components (CMYK-like, colorspace != YCbCr => every component is "luma" for
+    rebalance, reference quantsmooth.h:2639), RGB JPEGs, a component without a
+    quantisation table (skipped, reference :2493)"""
+    j = synth.synth_ycc(96, 72, 1, 1, quality=45, seed=2)
+    extra, q4 = synth.synth_gray(96, 72, 45, seed=8)
+    for cs, coefs, quants in ((4, j["coefs"] + [extra], j["quants"] + [q4]),      # JCS_CMYK
+                              (2, j["coefs"], j["quants"]),                        # JCS_RGB
+                              (3, j["coefs"], [j["quants"][0], None, j["quants"][2]])):
+        n = len(coefs)
+        kw = dict(hsamp=[1] * n, vsamp=[1] * n, colorspace=cs, image_size=(96, 72))
+        for flags in (0, 7, 32 | 1, 15):
+            a = gpu.do_quantsmooth(coefs, quants, flags, 2, **kw)
+            b = oracle.do_quantsmooth(coefs, quants, flags, 2, **kw)
+            assert_same_result(a, b, f"colorspace={cs} flags={flags}")
+
+
+def test_gpu_iteration_limits(gpu, oracle, synth):
+    """niter is clamped to [0, 100] (reference :2455-2456); niter 0 with UPSAMPLE_UV
+    still upsamples (reference :2458)"""
+    coef, quant = synth.synth_gray(24, 16, 50)
+    a = gpu.do_quantsmooth([coef], [quant], 0, 250)
+    b = oracle.do_quantsmooth([coef], [quant], 0, 250)
+    assert_same_result(a, b, "niter=250")
+    j = synth.synth_ycc(40, 24, 2, 2, quality=50)
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(40, 24))
+    a = gpu.do_quantsmooth(j["coefs"], j["quants"], 7, 0, **kw)
+    b = oracle.do_quantsmooth(j["coefs"], j["quants"], 7, 0, **kw)
+    assert a["up"] and b["up"]
+    assert_same_result(a, b, "niter=0 upsample")
+
+
+def test_gpu_max_plane_16384(gpu, synth):
+    """BASELINE config 3 size on one GPU: 16384 x 16384 luma (4.2 M blocks, 512 MiB
+    of coefficients): runs, stays inside the quantisation intervals, and a band
+    equals the same band computed from a cropped plane (locality)"""
+    import torch
+    import bench
+    dev = torch.device("cuda:0")
+    import jpegqs_pkg
+    pkg = jpegqs_pkg.load()
+    coef, quant = bench.synth_input_gpu(torch, pkg, 16384, 50, dev)
+    hb, wb = coef.shape[:2]
+    from jpeg_quantsmooth_amd import bands
+    eng = bands.HipBandEngine(gpu, torch, coef.clone(), quant, 0)
+    topo = bands.BandTopology(0, 1, 0, hb)
+    bands.run_band(eng, topo, 2, lambda: None)
+    torch.cuda.synchronize()
+    assert not eng.bad_coef()
+    sub = bands.HipBandEngine(gpu, torch, coef[1000:1016].clone(), quant, 0)
+    bands.run_band(sub, bands.BandTopology(0, 1, 0, 16), 2, lambda: None)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.coef[1003:1013], sub.coef[3:13])
+    q = torch.from_numpy(quant.astype(np.int32)).to(dev)
+    deq = coef.to(torch.int32) * q
+    g = eng.coef.to(torch.int32)
+    assert int(g.abs().max()) <= 1023
+    assert bool((((g - deq).abs() <= q // 2) | (g.abs() == 1023)).all())

@@ -807,6 +807,20 @@ __global__ void k_term9_sgprs(float* out, const float* tab, float a) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = num + den;
 }
 
+
+__global__ void k_dot2c(int* out, int a) {
+  int x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+  for (int i = 0; i < ITER; ++i) {
+    asm volatile(
+      "v_dot2c_i32_i16 %0, 0xd6301151, %8\n v_dot2c_i32_i16 %1, 0xd6301151, %8\n v_dot2c_i32_i16 %2, 0xd6301151, %8\n v_dot2c_i32_i16 %3, 0xd6301151, %8\n"
+      "v_dot2c_i32_i16 %4, 0xd6301151, %8\n v_dot2c_i32_i16 %5, 0xd6301151, %8\n v_dot2c_i32_i16 %6, 0xd6301151, %8\n v_dot2c_i32_i16 %7, 0xd6301151, %8\n"
+      "v_dot2c_i32_i16 %0, 0x12341151, %8\n v_dot2c_i32_i16 %1, 0x12341151, %8\n v_dot2c_i32_i16 %2, 0x12341151, %8\n v_dot2c_i32_i16 %3, 0x12341151, %8\n"
+      "v_dot2c_i32_i16 %4, 0x12341151, %8\n v_dot2c_i32_i16 %5, 0x12341151, %8\n v_dot2c_i32_i16 %6, 0x12341151, %8\n v_dot2c_i32_i16 %7, 0x12341151, %8\n"
+      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+
 template <class K, class T>
 static void run(const char* name, K kern, T* out, T arg, double lane_ops_per_thread_iter, int pk) {
   for (int wps = 1; wps <= 8; wps *= 2) {
@@ -865,6 +879,7 @@ int main() {
   run("term9 body1024", k_term9_big<1024>, out, 0.5f, 36, 1);
   run("sub|abs|+max", k_sub_abs_max, out, 1.0001f, 16, 1);
   run("mul_lo_u32", k_mul_lo, (int*)out, 3, 16, 1);
+  run("dot2c_i32_i16", k_dot2c, (int*)out, 3, 16, 1);
   run("mul/mad_i24", k_mul_i24, (int*)out, 3, 16, 1);
   run("dep_add", k_dep_add, out, 1.0001f, 16, 1);
   return 0;
