@@ -229,6 +229,15 @@ __device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
 #ifndef QS_PIN_DIFFS
 #define QS_PIN_DIFFS 1
 #endif
+// QS_PIN_EDGE=1 recomputes the 32 edge-pixel conversions at every anti-diagonal
+// (no scratch, HBM traffic close to algorithmic); 0 lets the compiler hoist them
+// out of the loop, where they end up in 124 B/lane of scratch.  Measured A/B on
+// MI355X (4096^2): 0 is 4 % faster at q3 and equal at q4 -- the kernel is
+// VALU-bound and the extra ~130 MB/launch of scratch traffic (<2 % of HBM peak)
+// is cheaper than 900 more VALU instructions per block.  Default: the fast one.
+#ifndef QS_PIN_EDGE
+#define QS_PIN_EDGE 0
+#endif
 // Explicit double-buffered scalar weight prefetch (QS_STEP below).  Measured on
 // MI355X: it makes 2-3 waves/SIMD as fast as 4, but at 4 waves/SIMD (the
 // default) the compiler's own s_load placement is already covered by the other
@@ -349,6 +358,11 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
         for (int j = 0; j < 8; ++j) px[y * 8 + j] = (float)o[j] * QS_PIX_SCALE;
       }
       // the 32 edge differences only change here, not per coefficient
+      // (see QS_PIN_EDGE above for the optional opaque barrier)
+#if QS_PIN_EDGE
+#pragma unroll
+      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(edge[e]));
+#endif
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
         bd[x]      = px[x]         - byte_f(edge[0 + (x >> 2)], x & 3) * QS_PIX_SCALE;
@@ -515,6 +529,12 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
 
   // ---- write back, coalesced; optional final +-1023 clamp (reference :2680-2686)
   {
+    // recompute the per-lane store addresses from an opaque copy of the lane
+    // id, so that the 8 load addresses of the prologue do not stay live (and
+    // get spilled) across the whole kernel
+    int lane2 = lane;
+    asm volatile("" : "+v"(lane2));
+    const int lane = lane2;
     const int m0 = (lane & 7) * 4;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

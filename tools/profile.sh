@@ -18,5 +18,7 @@ pmc pmc_fetch FETCH_SIZE
 pmc pmc_write WRITE_SIZE
 find $W -name "*.csv" | while read f; do sz=$(stat -c %s "$f"); echo "$sz $f"; done
 for f in $(find $W -name "*kernel_stats.csv" -o -name "*counter_collection.csv"); do
-  d=$(echo $f | sed -e "s#^$W/##" -e "s#/.*##"); cp $f $OUT/${d}_$(basename $f); done
+  d=$(echo $f | sed -e "s#^$W/##" -e "s#/.*##")
+  # keep the header and the rows of our kernels only (torch's input-generation kernels are noise)
+  (head -1 $f; grep -E "qs_[a-z_]+kernel" $f) > $OUT/${d}_$(basename $f); done
 python $REPO/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1; cat $OUT/summary.txt
