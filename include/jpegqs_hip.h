@@ -72,6 +72,9 @@ typedef int (*qs_hip_progress_fn)(void *userdata, int cur, int max);
 int qs_hip_do_quantsmooth(qs_hip_job *job, int flags, int niter, int progprec,
 		qs_hip_progress_fn progress, void *userdata);
 void qs_hip_free(void *p);
+/* the job layer keeps freed device buffers in a process-wide cache (up to 6 GiB);
+ * this returns them to the driver */
+void qs_hip_release_cache(void);
 
 /* ---- plane layer (device pointers, async on `stream`) --------------------- */
 

@@ -17,10 +17,14 @@
 #include <stdarg.h>
 #include <math.h>
 #include <new>
+#include <mutex>
+#include <vector>
 
 #include "../../include/jpegqs_hip.h"
 #include "qs_device.h"
 #include "qs_launch.h"
+
+extern "C" void qs_hip_release_cache(void);
 
 // ---------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -259,51 +263,128 @@ extern "C" int qs_hip_fdct_plane(const uint8_t* d_pixels, size_t pitch, int16_t*
 
 // ---------------------------------------------------------------------------
 // job layer
+//
+// Two execution modes share one component routine:
+//  * careful  -- the reference's order: one component after the other, host
+//                sync after the first pass A of each (bad-coefficient stop,
+//                reference :2610) and after every iteration that reports
+//                progress.  Used whenever a progress callback is installed, and
+//                as the re-run path below.
+//  * eager    -- no callback: every component is enqueued without host syncs,
+//                independent components on their own HIP streams ("one
+//                component per stream", BASELINE config 1; chroma waits for
+//                luma through an event when JOINT_YUV/UPSAMPLE_UV couple them).
+//                The range-check flags are read once at the end; nothing is
+//                copied back before that.  If any flag is set (crafted or
+//                damaged file) the job is simply re-run in careful mode from
+//                the untouched host input, which reproduces the reference's
+//                stop semantics exactly.
+// Device buffers come from a small process-wide cache (hipMalloc/hipFree of
+// 100+ MiB cost milliseconds each); qs_hip_release_cache() empties it.
 
 namespace {
 
+struct CacheEntry { void* p; size_t n; };
+static std::mutex g_cache_mu;
+static std::vector<CacheEntry> g_cache;            // free device blocks
+static const size_t kCacheMaxBytes = (size_t)6 << 30;
+
+static size_t round_size(size_t n) {               // size classes: powers of two from 64 KiB
+  size_t c = (size_t)64 << 10;
+  while (c < n) c <<= 1;
+  return c;
+}
+
 struct DevBuf {
   void* p = nullptr;
+  size_t n = 0;
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t n) { return hipMalloc(&p, n); }
-  void take(DevBuf& o) { if (p) (void)hipFree(p); p = o.p; o.p = nullptr; }
+  ~DevBuf() { release(); }
+  hipError_t alloc(size_t bytes) {
+    release();
+    const size_t want = round_size(bytes);
+    {
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      for (size_t i = 0; i < g_cache.size(); ++i)
+        if (g_cache[i].n == want) { p = g_cache[i].p; n = want; g_cache.erase(g_cache.begin() + i); return hipSuccess; }
+    }
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {                         // make room and retry once
+      (void)hipGetLastError();
+      qs_hip_release_cache();
+      e = hipMalloc(&p, want);
+    }
+    if (e == hipSuccess) n = want; else p = nullptr;
+    return e;
+  }
+  void release() {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    size_t held = 0;
+    for (auto& c : g_cache) held += c.n;
+    if (held + n <= kCacheMaxBytes) g_cache.push_back({p, n}); else (void)hipFree(p);
+    p = nullptr; n = 0;
+  }
+  void take(DevBuf& o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-struct Stream {
-  hipStream_t s = nullptr;
-  ~Stream() { if (s) (void)hipStreamDestroy(s); }
+struct Streams {
+  hipStream_t s[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t luma_done = nullptr;
+  ~Streams() {
+    for (auto& x : s) if (x) (void)hipStreamDestroy(x);
+    if (luma_done) (void)hipEventDestroy(luma_done);
+  }
 };
 
-}  // namespace
+static std::vector<Streams*> g_stream_pool;
 
-extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int progprec,
-                                     qs_hip_progress_fn progress, void* userdata) {
-  if (!job || job->ncomp < 1 || job->ncomp > QS_HIP_MAXC)
-    return fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: bad job");
-  for (int ci = 0; ci < job->ncomp; ++ci)
-    if (!job->coef[ci] || job->wblk[ci] <= 0 || job->hblk[ci] <= 0)
-      return fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: component %d has no data", ci);
+struct StreamLease {     // borrow a ready-made set of streams, give it back on scope exit
+  Streams* p = nullptr;
+  StreamLease() {
+    {
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      if (!g_stream_pool.empty()) { p = g_stream_pool.back(); g_stream_pool.pop_back(); return; }
+    }
+    Streams* n = new (std::nothrow) Streams;
+    if (!n) return;
+    bool ok = true;
+    for (int i = 0; i < 3 && ok; ++i) ok = hipStreamCreateWithFlags(&n->s[i], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&n->luma_done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { delete n; return; }
+    p = n;
+  }
+  ~StreamLease() {
+    if (!p) return;
+    for (auto& x : p->s) (void)hipStreamSynchronize(x);   // nothing of this job may outlive it
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_stream_pool.push_back(p);
+  }
+};
 
-  job->up_wblk = job->up_hblk = 0; job->coef_up[0] = job->coef_up[1] = nullptr;
-  job->out_hsamp0 = job->hsamp[0]; job->out_vsamp0 = job->vsamp[0];
+struct Comp {            // per-component device state (kept until the job ends)
+  DevBuf coef, plane, cst, status, up, px;
+  bool processed = false, dequant_only = false, have_up = false;
+  hipStream_t stream = nullptr;
+};
 
+enum { JOB_RERUN_CAREFUL = -1000 };
+
+static int run_job(qs_hip_job* job, int flags, int niter, int progprec,
+                   qs_hip_progress_fn progress, void* userdata, bool eager) {
   int need_lowres = 0, stop = 0;
   if ((flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV)) && job->colorspace == 3 && job->ncomp >= 3 &&
       job->hsamp[1] == 1 && job->vsamp[1] == 1 && job->hsamp[2] == 1 && job->vsamp[2] == 1)
     need_lowres = 1;                                     // reference :2447-2453
-  if (niter < 0) niter = 0;
-  if (niter > 100) niter = 100;                          // reference :2455-2456
-  if (niter <= 0 && !((flags & QS_UPSAMPLE_UV) && need_lowres)) return 0;  // reference :2458
 
-  if (qs_hip_device_count() <= 0)
-    return fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
-
-  Stream st;
-  HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+  // streams/events are pooled too (creating three streams costs ~1 ms)
+  StreamLease lease;
+  if (!lease.p) return fail(QS_HIP_ENODEV, "could not create HIP streams: %s", hipGetErrorString(hipGetLastError()));
+  Streams& st = *lease.p;
+  const int nstreams = eager ? 3 : 1;
 
   int prog_next = 0, prog_max = 0, prog_thr = 0;
   if (progress) {                                        // reference :2474-2482
@@ -313,10 +394,11 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
     prog_thr = (int)((unsigned)(prog_max + progprec - 1) / (unsigned)progprec);
   }
 
-  QsConsts* hc = new (std::nothrow) QsConsts;
+  QsConsts* hc = new (std::nothrow) QsConsts[QS_HIP_MAXC];   // one per component: uploads are async
   if (!hc) return fail(QS_HIP_ENOMEM, "out of host memory");
-  struct HcFree { QsConsts* p; ~HcFree() { delete p; } } hc_free{hc};
+  struct HcFree { QsConsts* p; ~HcFree() { delete[] p; } } hc_free{hc};
 
+  Comp comp[QS_HIP_MAXC];
   // planes that outlive their component (reference image1 / image2, :2753-2815)
   DevBuf d_yfull, d_llow;          // full-res luma plane; luma at chroma resolution
   bool have_yfull = false, have_llow = false;
@@ -324,6 +406,7 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
   struct UpFree { int16_t** p; bool keep; ~UpFree() { if (!keep) { free(p[0]); free(p[1]); } } } up_free{up_host, false};
 
   for (int ci = 0; ci < job->ncomp; ++ci) {
+    Comp& C = comp[ci];
     const int wb = job->wblk[ci], hb = job->hblk[ci];
     const size_t nblk = (size_t)wb * hb, cbytes = nblk * 64 * sizeof(int16_t);
     int iters = niter, extra = 0;
@@ -340,28 +423,32 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
     if (acc >= 0x800) stop = 1;                          // reference :2504
     if (iters + extra == 0) continue;                    // reference :2542
 
-    DevBuf d_coef, d_plane, d_cst, d_status;
-    HIP_TRY(d_coef.alloc(cbytes));
-    HIP_TRY(d_cst.alloc(sizeof(QsConsts)));
-    HIP_TRY(d_status.alloc(sizeof(int32_t)));
-    if (int r = qs_hip_consts_build(hc, job->quant[ci], flags)) return r;
-    HIP_TRY(hipMemcpyAsync(d_cst.p, hc, sizeof(QsConsts), hipMemcpyHostToDevice, st.s));
-    HIP_TRY(hipMemcpyAsync(d_coef.p, job->coef[ci], cbytes, hipMemcpyHostToDevice, st.s));
-    HIP_TRY(hipMemsetAsync(d_status.p, 0, sizeof(int32_t), st.s));
+    // stream: luma (and anything coupled to it) on stream 0; independent
+    // components round-robin
+    hipStream_t s = st.s[eager ? ci % nstreams : 0];
+    C.stream = s; C.processed = true;
+    HIP_TRY(C.coef.alloc(cbytes));
+    HIP_TRY(C.cst.alloc(sizeof(QsConsts)));
+    HIP_TRY(C.status.alloc(sizeof(int32_t)));
+    if (int r = qs_hip_consts_build(&hc[ci], job->quant[ci], flags)) return r;
+    HIP_TRY(hipMemcpyAsync(C.cst.p, &hc[ci], sizeof(QsConsts), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(C.coef.p, job->coef[ci], cbytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(C.status.p, 0, sizeof(int32_t), s));
 
     bool have_plane = false;
     if (!stop) {
       // the reference falls back to dequantise-only when the plane cannot be
       // allocated (reference :2551-2566); same here for device memory
-      hipError_t e = d_plane.alloc(qs_hip_plane_bytes(wb, hb));
+      hipError_t e = C.plane.alloc(qs_hip_plane_bytes(wb, hb));
       if (e == hipSuccess) have_plane = true; else (void)hipGetLastError();
     }
     if (!have_plane) {
-      if (int r = qs_hip_dequant_plane(d_cst.p, d_coef.as<int16_t>(), wb, hb, st.s)) return r;
-      HIP_TRY(hipMemcpyAsync(job->coef[ci], d_coef.p, cbytes, hipMemcpyDeviceToHost, st.s));
-      HIP_TRY(hipStreamSynchronize(st.s));
+      C.dequant_only = true;
+      if (int r = qs_hip_dequant_plane(C.cst.p, C.coef.as<int16_t>(), wb, hb, s)) return r;
       continue;
     }
+    if (eager && ci > 0 && (have_llow || have_yfull))    // chroma reads planes produced on the luma stream
+      HIP_TRY(hipStreamWaitEvent(s, st.luma_done, 0));
 
     const int rebalance = !(flags & QS_NO_REBALANCE) && (luma || !(flags & QS_NO_REBALANCE_UV));  // :1567-1568
     // JOINT_YUV acts through the low-res luma plane only (reference :2636)
@@ -369,12 +456,12 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
     const int plane_flags = flags & (QS_DIAGONALS | QS_NO_REBALANCE | QS_NO_REBALANCE_UV);
     bool clamped = false;
     for (int it = 0; it < iters + extra; ++it) {
-      if (int r = qs_hip_idct_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), wb, hb,
-                                    it == 0, 1, 1, d_status.as<int32_t>(), st.s)) return r;
-      if (it == 0) {                                     // reference :2610
+      if (int r = qs_hip_idct_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), wb, hb,
+                                    it == 0, 1, 1, C.status.as<int32_t>(), s)) return r;
+      if (it == 0 && !eager) {                           // reference :2610
         int32_t bad = 0;
-        HIP_TRY(hipMemcpyAsync(&bad, d_status.p, sizeof(bad), hipMemcpyDeviceToHost, st.s));
-        HIP_TRY(hipStreamSynchronize(st.s));
+        HIP_TRY(hipMemcpyAsync(&bad, C.status.p, sizeof(bad), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
         if (bad) { stop = 1; break; }
       }
       if (it == iters) break;                            // refresh-only pass, reference :2622
@@ -382,18 +469,18 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
       const int last = (it == iters - 1);
       if (flags & QS_LOW_QUALITY) {                      // reference :924-938: never reaches the k-loop
         if (joint) {
-          if (int r = qs_hip_joint_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), d_llow.as<uint8_t>(),
-                                         wb, hb, rebalance, last, st.s)) return r;
+          if (int r = qs_hip_joint_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), d_llow.as<uint8_t>(),
+                                         wb, hb, rebalance, last, s)) return r;
         } else {
-          if (int r = qs_hip_lowq_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), wb, hb,
-                                        rebalance, last, st.s)) return r;
+          if (int r = qs_hip_lowq_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), wb, hb,
+                                        rebalance, last, s)) return r;
         }
       } else {
         if (joint)
-          if (int r = qs_hip_joint_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), d_llow.as<uint8_t>(),
-                                         wb, hb, 0, 0, st.s)) return r;
-        if (int r = qs_hip_smooth_plane(d_cst.p, d_coef.as<int16_t>(), d_plane.as<uint8_t>(), wb, hb,
-                                        plane_flags, luma, last, st.s)) return r;
+          if (int r = qs_hip_joint_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), d_llow.as<uint8_t>(),
+                                         wb, hb, 0, 0, s)) return r;
+        if (int r = qs_hip_smooth_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), wb, hb,
+                                        plane_flags, luma, last, s)) return r;
       }
       if (last) clamped = true;
       if (progress) {                                    // reference :2656-2664
@@ -401,49 +488,69 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
         if (cur >= prog_thr) {
           cur = (int)((long long)progprec * cur / prog_max);
           prog_thr = (int)(((long long)(cur + 1) * prog_max + progprec - 1) / progprec);
-          HIP_TRY(hipStreamSynchronize(st.s));           // the pass is done when we report it
+          HIP_TRY(hipStreamSynchronize(s));              // the pass is done when we report it
           stop = progress(userdata, cur, progprec);
         }
         if (stop) break;
       }
     }
     if (!clamped)                                        // reference :2668-2689
-      if (int r = qs_hip_clamp_plane(d_coef.as<int16_t>(), wb, hb, st.s)) return r;
-    HIP_TRY(hipMemcpyAsync(job->coef[ci], d_coef.p, cbytes, hipMemcpyDeviceToHost, st.s));
+      if (int r = qs_hip_clamp_plane(C.coef.as<int16_t>(), wb, hb, s)) return r;
 
     if (!stop && have_yfull) {
       // UPSAMPLE_UV: chroma -> luma resolution, re-encoded (reference :2691-2752)
       const int ws = job->hsamp[0], hs = job->vsamp[0];
       const int uwb = job->wblk[0], uhb = job->hblk[0];
       const size_t ubytes = (size_t)uwb * uhb * 64 * sizeof(int16_t);
-      DevBuf d_px, d_up;
-      HIP_TRY(d_px.alloc(qs_hip_upsample_bytes(job->image_width, job->image_height, ws, hs)));
-      HIP_TRY(d_up.alloc(ubytes));
+      HIP_TRY(C.px.alloc(qs_hip_upsample_bytes(job->image_width, job->image_height, ws, hs)));
+      HIP_TRY(C.up.alloc(ubytes));
       up_host[ci - 1] = static_cast<int16_t*>(malloc(ubytes));
       if (!up_host[ci - 1]) return fail(QS_HIP_ENOMEM, "out of host memory");
-      if (int r = qs_hip_upsample_plane(d_plane.as<uint8_t>(), d_llow.as<uint8_t>(), wb, d_yfull.as<uint8_t>(),
-                                        uwb, uhb, d_px.as<uint8_t>(), job->image_width, job->image_height,
-                                        ws, hs, st.s)) return r;
-      if (int r = qs_hip_fdct_plane(d_px.as<uint8_t>(), qs_hip_upsample_pitch(job->image_width, ws),
-                                    d_up.as<int16_t>(), uwb, uhb, st.s)) return r;
-      HIP_TRY(hipMemcpyAsync(up_host[ci - 1], d_up.p, ubytes, hipMemcpyDeviceToHost, st.s));
-      HIP_TRY(hipStreamSynchronize(st.s));
+      if (int r = qs_hip_upsample_plane(C.plane.as<uint8_t>(), d_llow.as<uint8_t>(), wb, d_yfull.as<uint8_t>(),
+                                        uwb, uhb, C.px.as<uint8_t>(), job->image_width, job->image_height,
+                                        ws, hs, s)) return r;
+      if (int r = qs_hip_fdct_plane(C.px.as<uint8_t>(), qs_hip_upsample_pitch(job->image_width, ws),
+                                    C.up.as<int16_t>(), uwb, uhb, s)) return r;
+      C.have_up = true;
     } else if (!stop && !ci && need_lowres) {
       // keep luma for the chroma passes (reference :2753-2815)
       const int ws = job->hsamp[0], hs = job->vsamp[0];
       if (ws == 1 && hs == 1) {
-        d_llow.take(d_plane); have_llow = true;          // image2 = image
+        d_llow.take(C.plane); have_llow = true;          // image2 = image
       } else {
         DevBuf d_l;
         HIP_TRY(d_l.alloc(qs_hip_plane_bytes(job->wblk[1], job->hblk[1])));
-        if (int r = qs_hip_downsample_plane(d_plane.as<uint8_t>(), wb, hb, d_l.as<uint8_t>(),
-                                            job->wblk[1], job->hblk[1], ws, hs, st.s)) return r;
+        if (int r = qs_hip_downsample_plane(C.plane.as<uint8_t>(), wb, hb, d_l.as<uint8_t>(),
+                                            job->wblk[1], job->hblk[1], ws, hs, s)) return r;
         d_llow.take(d_l); have_llow = true;
-        if (flags & QS_UPSAMPLE_UV) { d_yfull.take(d_plane); have_yfull = true; }   // image1 = image
+        if (flags & QS_UPSAMPLE_UV) { d_yfull.take(C.plane); have_yfull = true; }   // image1 = image
       }
+      HIP_TRY(hipEventRecord(st.luma_done, s));
     }
-    HIP_TRY(hipStreamSynchronize(st.s));
+    if (!eager) HIP_TRY(hipStreamSynchronize(s));
   }
+
+  // ---- everything is enqueued; eager mode reads the range-check flags now
+  for (int i = 0; i < nstreams; ++i) HIP_TRY(hipStreamSynchronize(st.s[i]));
+  if (eager)
+    for (int ci = 0; ci < job->ncomp; ++ci)
+      if (comp[ci].processed && !comp[ci].dequant_only) {
+        int32_t bad = 0;
+        HIP_TRY(hipMemcpy(&bad, comp[ci].status.p, sizeof(bad), hipMemcpyDeviceToHost));
+        if (bad) return JOB_RERUN_CAREFUL;               // host input is still untouched
+      }
+
+  // ---- copy results back (the only place host memory is written)
+  for (int ci = 0; ci < job->ncomp; ++ci) {
+    Comp& C = comp[ci];
+    if (!C.processed) continue;
+    const size_t cbytes = (size_t)job->wblk[ci] * job->hblk[ci] * 64 * sizeof(int16_t);
+    HIP_TRY(hipMemcpyAsync(job->coef[ci], C.coef.p, cbytes, hipMemcpyDeviceToHost, st.s[0]));
+    if (C.have_up && !stop)
+      HIP_TRY(hipMemcpyAsync(up_host[ci - 1], C.up.p, (size_t)job->wblk[0] * job->hblk[0] * 64 * sizeof(int16_t),
+                             hipMemcpyDeviceToHost, st.s[0]));
+  }
+  HIP_TRY(hipStreamSynchronize(st.s[0]));
 
   if (!stop && have_yfull && up_host[0] && up_host[1]) {  // reference :2836-2849
     job->coef_up[0] = up_host[0]; job->coef_up[1] = up_host[1]; up_free.keep = true;
@@ -453,4 +560,42 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
   for (int ci = 0; ci < job->ncomp; ++ci)                // reference :2851-2859
     if (job->has_quant[ci]) for (int i = 0; i < 64; ++i) job->quant[ci][i] = 1;
   return stop;
+}
+
+}  // namespace
+
+extern "C" void qs_hip_release_cache(void) {
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  for (auto& c : g_cache) (void)hipFree(c.p);
+  g_cache.clear();
+  for (auto* sp : g_stream_pool) delete sp;
+  g_stream_pool.clear();
+}
+
+extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int progprec,
+                                     qs_hip_progress_fn progress, void* userdata) {
+  if (!job || job->ncomp < 1 || job->ncomp > QS_HIP_MAXC)
+    return fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: bad job");
+  for (int ci = 0; ci < job->ncomp; ++ci)
+    if (!job->coef[ci] || job->wblk[ci] <= 0 || job->hblk[ci] <= 0)
+      return fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: component %d has no data", ci);
+
+  job->up_wblk = job->up_hblk = 0; job->coef_up[0] = job->coef_up[1] = nullptr;
+  job->out_hsamp0 = job->hsamp[0]; job->out_vsamp0 = job->vsamp[0];
+
+  int need_lowres = 0;
+  if ((flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV)) && job->colorspace == 3 && job->ncomp >= 3 &&
+      job->hsamp[1] == 1 && job->vsamp[1] == 1 && job->hsamp[2] == 1 && job->vsamp[2] == 1)
+    need_lowres = 1;                                     // reference :2447-2453
+  if (niter < 0) niter = 0;
+  if (niter > 100) niter = 100;                          // reference :2455-2456
+  if (niter <= 0 && !((flags & QS_UPSAMPLE_UV) && need_lowres)) return 0;  // reference :2458
+
+  if (qs_hip_device_count() <= 0)
+    return fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+
+  int r = run_job(job, flags, niter, progprec, progress, userdata, /*eager=*/progress == nullptr);
+  if (r == JOB_RERUN_CAREFUL)
+    r = run_job(job, flags, niter, progprec, progress, userdata, /*eager=*/false);
+  return r;
 }

@@ -66,6 +66,7 @@ PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
 ABI = {
     "qs_hip_do_quantsmooth": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int, C.c_int, PROGRESS_FN, C.c_void_p]),
     "qs_hip_free": (None, [C.c_void_p]),
+    "qs_hip_release_cache": (None, []),
     "qs_hip_device_count": (C.c_int, []),
     "qs_hip_last_error": (C.c_char_p, []),
     "qs_hip_consts_bytes": (C.c_size_t, []),
