@@ -103,6 +103,53 @@ __device__ __forceinline__ void idct_pass2_row(uint32_t (&row)[8], int (&out)[8]
 }
 
 // --------------------------------------------------------------------------
+// QS_IDCT_DOT2: column pass of the refresh IDCT on packed int16 pairs.
+// In the recovery kernel the 64 coefficients of a block sit in LDS as 32
+// dwords.  With this option dword m = 4*x + t of a lane's column holds, for
+// block column x, the pair  t=0: (c0,c4)  t=1: (c2,c6)  t=2: (c7,c5)  t=3: (c3,c1)
+// (first = low half; cN = coefficient in row N), which is what the LL&M
+// butterfly consumes together: every partial sum of the column pass is a
+// 2-term dot product with constant int16 weights -> v_dot2c_i32_i16, one
+// instruction for two multiplies and two adds (the odd part is expanded into
+// its 4x4 integer matrix).  Integer ring arithmetic, so the regrouping is exact
+// (no overflow either: |coef| <= 3071 inside the recovery loop).
+// Measured on MI355X (A/B in one run, 4096^2): bit-exact, but not faster --
+// q3 0.541 vs 0.537 ms, q4 0.818 vs 0.793 ms: v_dot2c_i32_i16 issues at the
+// same half rate as v_mul_i32_i24 (tools/ubench_valu.hip) and the accumulator
+// v_movs plus the extra register pressure eat the saved adds.  Off by default;
+// kept as a checked-in negative result.
+#ifndef QS_IDCT_DOT2
+#define QS_IDCT_DOT2 0
+#endif
+typedef short qs_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2(uint32_t pair, int klo, int khi, int acc) {
+  const qs_s2 k = {(short)klo, (short)khi};
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(qs_s2, pair), k, acc, false);
+}
+// row of a coefficient -> (pair slot t, half h) of the layout above
+__device__ __forceinline__ constexpr int pair_slot(int r) { return r == 0 || r == 4 ? 0 : r == 2 || r == 6 ? 1 : r == 7 || r == 5 ? 2 : 3; }
+__device__ __forceinline__ constexpr int pair_half(int r) { return (r == 4 || r == 6 || r == 5 || r == 1) ? 1 : 0; }
+
+// one column: four packed pairs in, eight workspace values out (descaled by 11
+// with the rounding bias folded into the accumulators)
+__device__ __forceinline__ void idct_col_dot2(uint32_t p04, uint32_t p26, uint32_t p75, uint32_t p31, uint32_t (&o)[8]) {
+  const int t0 = dot2(p04, 8192, 8192, 1024);      // (c0 + c4) << 13, + rounding
+  const int t1 = dot2(p04, 8192, -8192, 1024);     // (c0 - c4) << 13, + rounding
+  const int t2 = dot2(p26, 4433, -10704, 0);       // z1 - c6 * 15137
+  const int t3 = dot2(p26, 10703, 4433, 0);        // z1 + c2 * 6270
+  const int e0 = t0 + t3, e3 = t0 - t3, e1 = t1 + t2, e2 = t1 - t2;
+  // odd part as a 4x4 integer matrix on (c7, c5, c3, c1)
+  const int q0 = dot2(p31, -6436, 2260, dot2(p75, -11363, 9633, 0));
+  const int q1 = dot2(p31, -11362, 6437, dot2(p75, 9633, 2261, 0));
+  const int q2 = dot2(p31, -2259, 9633, dot2(p75, -6436, -11362, 0));
+  const int q3 = dot2(p31, 9633, 11363, dot2(p75, 2260, 6437, 0));
+  o[0] = (uint32_t)((e0 + q3) >> 11); o[7] = (uint32_t)((e0 - q3) >> 11);
+  o[1] = (uint32_t)((e1 + q2) >> 11); o[6] = (uint32_t)((e1 - q2) >> 11);
+  o[2] = (uint32_t)((e2 + q1) >> 11); o[5] = (uint32_t)((e2 - q1) >> 11);
+  o[3] = (uint32_t)((e3 + q0) >> 11); o[4] = (uint32_t)((e3 - q0) >> 11);
+}
+
+// --------------------------------------------------------------------------
 // Kernel A: (dequantise +) IDCT every block into the pixel plane and write the
 // clamp-to-edge apron.  One block per lane; consecutive lanes take consecutive
 // blocks of a block row so the 8-byte pixel-row stores of a wave coalesce into
@@ -191,12 +238,24 @@ qs_idct_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coe
 // 32-bit accesses used for staging and for the IDCT refresh, and the compiler
 // must not reorder one kind across the other (it does under strict aliasing).
 typedef int16_t __attribute__((may_alias)) lds_i16;
+__device__ __forceinline__ int lds_halfword(int i) {   // index of coefficient i in 16-bit units, pitch aside
+#if QS_IDCT_DOT2
+  const int r = i >> 3, x = i & 7;
+  const int t = (0x21203130 >> (4 * r)) & 3;         // rows {0,4}->0 {2,6}->1 {7,5}->2 {3,1}->3
+  const int h = (0x72 >> r) & 1;                      // rows 1, 4, 5, 6 are the high half
+  return ((x * 4 + t) << 1) | h;
+#else
+  return i;
+#endif
+}
 __device__ __forceinline__ int lds_coef(const uint32_t* col, int i) {
-  const lds_i16* p = reinterpret_cast<const lds_i16*>(col + (i >> 1) * QS_LDS_PITCH) + (i & 1);
+  const int hw = lds_halfword(i);
+  const lds_i16* p = reinterpret_cast<const lds_i16*>(col + (hw >> 1) * QS_LDS_PITCH) + (hw & 1);
   return *p;
 }
 __device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
-  lds_i16* p = reinterpret_cast<lds_i16*>(col + (i >> 1) * QS_LDS_PITCH) + (i & 1);
+  const int hw = lds_halfword(i);
+  lds_i16* p = reinterpret_cast<lds_i16*>(col + (hw >> 1) * QS_LDS_PITCH) + (hw & 1);
   *p = (lds_i16)v;
 }
 
@@ -319,6 +378,24 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
     edge[7] = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
   }
   wave_lds_sync();
+#if QS_IDCT_DOT2
+  {  // row-major pairs (c[r][2j], c[r][2j+1]) -> column pairs of QS_IDCT_DOT2, in place, own column only
+    uint32_t rm[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) rm[m] = col[m * QS_LDS_PITCH];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      constexpr int ra[4] = {0, 2, 7, 3}, rb[4] = {4, 6, 5, 1};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t a = rm[ra[t] * 4 + (x >> 1)], b = rm[rb[t] * 4 + (x >> 1)];
+        const uint32_t lo = (x & 1) ? (a >> 16) : (a & 0xffffu);
+        const uint32_t hi = (x & 1) ? (b & 0xffff0000u) : (b << 16);
+        col[(4 * x + t) * QS_LDS_PITCH] = lo | hi;
+      }
+    }
+  }
+#endif
 
   constexpr int TS = DIAG ? 272 : 160;
   float px[64];   // own pixels * 2^-12
@@ -341,6 +418,16 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
 #endif
     {
       uint32_t ws[64];
+#if QS_IDCT_DOT2
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        uint32_t o[8];
+        idct_col_dot2(col[(4 * x + 0) * QS_LDS_PITCH], col[(4 * x + 1) * QS_LDS_PITCH],
+                      col[(4 * x + 2) * QS_LDS_PITCH], col[(4 * x + 3) * QS_LDS_PITCH], o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ws[j * 8 + x] = o[j];
+      }
+#else
 #pragma unroll
       for (int m = 0; m < 32; ++m) {
         const uint32_t d = col[m * QS_LDS_PITCH];
@@ -348,6 +435,7 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
         ws[2 * m + 1] = (uint32_t)((int32_t)d >> 16);
       }
       idct_pass1(ws);
+#endif
 #pragma unroll
       for (int y = 0; y < 8; ++y) {
         uint32_t row[8]; int o[8];
@@ -525,6 +613,24 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
       }
     }
   }
+#if QS_IDCT_DOT2
+  {  // back to row-major pairs for the coalesced write-back
+    uint32_t cp[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) cp[m] = col[m * QS_LDS_PITCH];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int t = pair_slot(r), h = pair_half(r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t a = cp[4 * (2 * j) + t], b = cp[4 * (2 * j + 1) + t];
+        const uint32_t lo = h ? (a >> 16) : (a & 0xffffu);
+        const uint32_t hi = h ? (b & 0xffff0000u) : (b << 16);
+        col[(r * 4 + j) * QS_LDS_PITCH] = lo | hi;
+      }
+    }
+  }
+#endif
   wave_lds_sync();
 
   // ---- write back, coalesced; optional final +-1023 clamp (reference :2680-2686)
