@@ -107,6 +107,10 @@ int qs_hip_idct_plane(const void *d_consts, int16_t *d_coef, uint8_t *d_plane,
  * Supported here: flags & (DIAGONALS | NO_REBALANCE | NO_REBALANCE_UV). */
 int qs_hip_smooth_plane(const void *d_consts, int16_t *d_coef, const uint8_t *d_plane,
 		int wblk, int hblk, int flags, int luma, int final_clamp, void *stream);
+/* the same for block rows [row0, row1) only: a band runs its interior rows while
+ * the halo rows are still in flight and its first/last row afterwards */
+int qs_hip_smooth_rows(const void *d_consts, int16_t *d_coef, const uint8_t *d_plane,
+		int wblk, int hblk, int row0, int row1, int flags, int luma, int final_clamp, void *stream);
 
 /* JOINT_YUV chroma predictor + fdct_clamp for one chroma plane (reference :577-579,
  * 893-921, 343-347, 551-561); d_luma_lowres = luma at this plane's resolution and

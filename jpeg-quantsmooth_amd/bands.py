@@ -66,6 +66,7 @@ class BandEngine:
 
     def idct(self, first: bool, rep_top: int, rep_bot: int) -> None: ...
     def smooth(self, final_clamp: bool) -> None: ...
+    def smooth_rows(self, row0: int, row1: int, final_clamp: bool) -> None: ...
     def row(self, y: int):
         """1-D uint8 tensor aliasing pixel row y of the band's plane, apron
         columns included; y = -1 and y = hblk*8 are the apron (halo) rows"""
@@ -97,11 +98,41 @@ def exchange_halo_local(engines) -> None:
 
 
 def run_band(engine: BandEngine, topo: BandTopology, niter: int, exchange) -> None:
-    """one complete smoothing of the band: niter x {pass A, halo, pass B}"""
+    """one complete smoothing of the band: niter x {pass A, halo, pass B}
+    (simple schedule: the halo exchange sits between the two passes)"""
     for it in range(niter):
         engine.idct(it == 0, topo.rep_top, topo.rep_bot)
         exchange()
         engine.smooth(it == niter - 1)
+
+
+def run_band_overlapped(engine: BandEngine, topo: BandTopology, niter: int, exchange, comm=None) -> None:
+    """Same result, communication hidden: only the first and last block row of a
+    band read the halo rows, so pass B starts on the interior rows right after
+    pass A while the exchange is in flight, and finishes with the edge rows once
+    it has landed.  `comm` = (begin, end) callables that fork the exchange onto a
+    side stream and join it again (HipBandEngine.comm_scope); without it the
+    exchange is simply issued first (CPU engines)."""
+    hb = engine.hblk
+    lo = 1 if topo.up is not None else 0                    # edge rows that must wait
+    hi = hb - 1 if topo.down is not None else hb
+    if hi < lo:                                             # one-row band with two neighbours
+        lo, hi = 0, 0
+    for it in range(niter):
+        last = it == niter - 1
+        engine.idct(it == 0, topo.rep_top, topo.rep_bot)
+        if comm:
+            comm[0]()
+        exchange()
+        if comm:
+            comm[1](False)                                  # stay forked: do not join yet
+        engine.smooth_rows(lo, hi, last)                    # interior: no halo dependence
+        if comm:
+            comm[1](True)                                   # join: halo rows are in place
+        if lo > 0:
+            engine.smooth_rows(0, lo, last)
+        if hi < hb:
+            engine.smooth_rows(hi, hb, last)
 
 
 class HipBandEngine(BandEngine):
@@ -136,9 +167,37 @@ class HipBandEngine(BandEngine):
         self.hip.smooth_plane(self.cst.data_ptr(), self.coef.data_ptr(), self.plane.data_ptr(),
                               self.wblk, self.hblk, self.flags, self.luma, final_clamp, self._s())
 
+    def smooth_rows(self, row0, row1, final_clamp):
+        if row1 > row0:
+            self.hip.smooth_rows(self.cst.data_ptr(), self.coef.data_ptr(), self.plane.data_ptr(),
+                                 self.wblk, self.hblk, row0, row1, self.flags, self.luma, final_clamp, self._s())
+
     def row(self, y):
         o = self.hip.plane_row_offset(self.wblk, y)
         return self.plane[o:o + self.pitch]
 
     def bad_coef(self):
         return bool(int(self.status.item()))
+
+    def comm_scope(self):
+        """(begin, end) for run_band_overlapped: run the halo exchange on a side
+        stream that waits for pass A, and make the compute stream wait for it
+        only before the edge rows"""
+        torch = self.torch
+        if not hasattr(self, "_comm_stream"):
+            self._comm_stream = torch.cuda.Stream(device=self.plane.device)
+            self._ctx = None
+        main = self._stream if self._stream is not None else torch.cuda.current_stream()
+
+        def begin():
+            self._comm_stream.wait_stream(main)            # after pass A
+            self._ctx = torch.cuda.stream(self._comm_stream)
+            self._ctx.__enter__()                          # collectives issued now sync with the side stream
+
+        def end(join):
+            if self._ctx is not None:
+                self._ctx.__exit__(None, None, None)
+                self._ctx = None
+            if join:
+                main.wait_stream(self._comm_stream)
+        return begin, end

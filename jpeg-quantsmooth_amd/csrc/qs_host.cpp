@@ -179,16 +179,28 @@ extern "C" int qs_hip_idct_plane(const void* d_consts, int16_t* d_coef, uint8_t*
   return launch_status("qs_hip_idct_plane");
 }
 
-extern "C" int qs_hip_smooth_plane(const void* d_consts, int16_t* d_coef, const uint8_t* d_plane,
-                                   int wblk, int hblk, int flags, int luma, int final_clamp, void* stream) {
-  if (int r = check_plane_args(d_coef, d_plane, wblk, hblk, "qs_hip_smooth_plane")) return r;
-  if (!d_consts) return fail(QS_HIP_EINVAL, "qs_hip_smooth_plane: null consts");
+static int smooth_rows(const void* d_consts, int16_t* d_coef, const uint8_t* d_plane, int wblk, int hblk,
+                       int row0, int row1, int flags, int luma, int final_clamp, void* stream, const char* who) {
+  if (int r = check_plane_args(d_coef, d_plane, wblk, hblk, who)) return r;
+  if (!d_consts) return fail(QS_HIP_EINVAL, "%s: null consts", who);
+  if (row0 < 0 || row1 > hblk || row0 > row1) return fail(QS_HIP_EINVAL, "%s: bad row range %d..%d", who, row0, row1);
   if (flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV | QS_LOW_QUALITY))
-    return fail(QS_HIP_ENOTSUP, "qs_hip_smooth_plane: flags 0x%x need the joint/low-quality kernels", flags);
+    return fail(QS_HIP_ENOTSUP, "%s: flags 0x%x are handled by qs_hip_joint_plane / qs_hip_lowq_plane", who, flags);
   int rebalance = !(flags & QS_NO_REBALANCE) && (luma || !(flags & QS_NO_REBALANCE_UV)); // reference :1567-1568
   qs_launch_smooth_plane(static_cast<const QsConsts*>(d_consts), d_coef, d_plane, wblk, hblk,
-                         (flags & QS_DIAGONALS) != 0, rebalance, final_clamp, static_cast<hipStream_t>(stream));
-  return launch_status("qs_hip_smooth_plane");
+                         (flags & QS_DIAGONALS) != 0, rebalance, final_clamp, row0 * wblk, row1 * wblk,
+                         static_cast<hipStream_t>(stream));
+  return launch_status(who);
+}
+
+extern "C" int qs_hip_smooth_plane(const void* d_consts, int16_t* d_coef, const uint8_t* d_plane,
+                                   int wblk, int hblk, int flags, int luma, int final_clamp, void* stream) {
+  return smooth_rows(d_consts, d_coef, d_plane, wblk, hblk, 0, hblk, flags, luma, final_clamp, stream, "qs_hip_smooth_plane");
+}
+
+extern "C" int qs_hip_smooth_rows(const void* d_consts, int16_t* d_coef, const uint8_t* d_plane,
+                                  int wblk, int hblk, int row0, int row1, int flags, int luma, int final_clamp, void* stream) {
+  return smooth_rows(d_consts, d_coef, d_plane, wblk, hblk, row0, row1, flags, luma, final_clamp, stream, "qs_hip_smooth_rows");
 }
 
 extern "C" int qs_hip_clamp_plane(int16_t* d_coef, int wblk, int hblk, void* stream) {

@@ -330,13 +330,16 @@ template <bool DIAG>
 __global__ void __launch_bounds__(256, QS_SMOOTH_MIN_WAVES)
 qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
                        const uint8_t* __restrict__ plane, int wblk, int hblk, int pitch,
-                       int rebalance, int final_clamp) {
+                       int rebalance, int final_clamp, int blk_begin, int blk_end) {
+  // blocks [blk_begin, blk_end) of the plane (linear, row-major): the whole
+  // plane, or the interior / the edge block rows of a band when the halo
+  // exchange is overlapped with the interior (bands.py)
   __shared__ uint32_t lds_all[4][32 * QS_LDS_PITCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t* lds = lds_all[wave];
   uint32_t* col = lds + lane;
-  const int nblk = wblk * hblk;
-  const int base = (blockIdx.x * 4 + wave) * 64;
+  const int nblk = blk_end;
+  const int base = blk_begin + (blockIdx.x * 4 + wave) * 64;
   if (base >= nblk) return;  // wave-uniform
   const int nvec = min(64, nblk - base) * 8;
 
@@ -714,15 +717,16 @@ void qs_launch_idct_plane(const QsConsts* cst, int16_t* coef, uint8_t* plane, in
 }
 
 void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* plane, int wblk, int hblk,
-                            int diag, int rebalance, int final_clamp, hipStream_t s) {
-  const int nblk = wblk * hblk;
-  const dim3 grid((nblk + 255) / 256), block(256);
+                            int diag, int rebalance, int final_clamp, int blk_begin, int blk_end, hipStream_t s) {
+  const int n = blk_end - blk_begin;
+  if (n <= 0) return;
+  const dim3 grid((n + 255) / 256), block(256);
   if (diag)
     hipLaunchKernelGGL(qs_smooth_plane_kernel<true>, grid, block, 0, s,
-                       cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), rebalance, final_clamp);
+                       cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), rebalance, final_clamp, blk_begin, blk_end);
   else
     hipLaunchKernelGGL(qs_smooth_plane_kernel<false>, grid, block, 0, s,
-                       cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), rebalance, final_clamp);
+                       cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), rebalance, final_clamp, blk_begin, blk_end);
 }
 
 void qs_launch_clamp(int16_t* coef, size_t nblk, hipStream_t s) {

@@ -78,6 +78,8 @@ ABI = {
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "qs_hip_smooth_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_smooth_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_joint_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_lowq_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -219,6 +221,10 @@ class HipQS:
     def smooth_plane(self, d_consts, d_coef, d_plane, wblk, hblk, flags, luma=1, final_clamp=0, stream=None):
         self._check(self.lib.qs_hip_smooth_plane(d_consts, d_coef, d_plane, wblk, hblk, flags,
                                                  int(luma), int(final_clamp), stream))
+
+    def smooth_rows(self, d_consts, d_coef, d_plane, wblk, hblk, row0, row1, flags, luma=1, final_clamp=0, stream=None):
+        self._check(self.lib.qs_hip_smooth_rows(d_consts, d_coef, d_plane, wblk, hblk, row0, row1, flags,
+                                                int(luma), int(final_clamp), stream))
 
     def clamp_plane(self, d_coef, wblk, hblk, stream=None):
         self._check(self.lib.qs_hip_clamp_plane(d_coef, wblk, hblk, stream))

@@ -753,14 +753,23 @@ void qso_band_idct(int16_t *coef, int wblk, int hblk, const uint16_t rawq[64], i
 	if (isbad && bad) *bad = 1;
 }
 
+void qso_band_smooth_rows(int16_t *coef, int wblk, int hblk, const uint16_t rawq[64],
+		const uint8_t *plane, int pitch, int apron_x, int flags, int luma, int final_clamp, int row0, int row1);
+
 void qso_band_smooth(int16_t *coef, int wblk, int hblk, const uint16_t rawq[64],
 		const uint8_t *plane, int pitch, int apron_x, int flags, int luma, int final_clamp) {
+	qso_band_smooth_rows(coef, wblk, hblk, rawq, plane, pitch, apron_x, flags, luma, final_clamp, 0, hblk);
+}
+
+void qso_band_smooth_rows(int16_t *coef, int wblk, int hblk, const uint16_t rawq[64],
+		const uint8_t *plane, int pitch, int apron_x, int flags, int luma, int final_clamp, int row0, int row1) {
 	uint16_t q[64]; int by;
+	(void)hblk;
 	qso_quant_prep(rawq, q, NULL, NULL);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic)
 #endif
-	for (by = 0; by < hblk; by++) {
+	for (by = row0; by < row1; by++) {
 		int bx, j;
 		for (bx = 0; bx < wblk; bx++) {
 			int16_t *c = coef + ((size_t)by * wblk + bx) * 64;

@@ -69,6 +69,8 @@ void qso_band_idct(int16_t *coef, int wblk, int hblk, const uint16_t rawq[64], i
 		uint8_t *plane, int pitch, int apron_x, int rep_top, int rep_bot, int *bad);
 void qso_band_smooth(int16_t *coef, int wblk, int hblk, const uint16_t rawq[64],
 		const uint8_t *plane, int pitch, int apron_x, int flags, int luma, int final_clamp);
+void qso_band_smooth_rows(int16_t *coef, int wblk, int hblk, const uint16_t rawq[64],
+		const uint8_t *plane, int pitch, int apron_x, int flags, int luma, int final_clamp, int row0, int row1);
 
 #ifdef __cplusplus
 }

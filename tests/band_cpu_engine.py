@@ -36,8 +36,15 @@ class OracleBandEngine:
                    self.plane.data_ptr(), self.pitch, APRON_X, int(rep_top), int(rep_bot), C.byref(self._bad))
 
     def smooth(self, final_clamp):
-        self._smooth(self.coef.ctypes.data, self.wblk, self.hblk, self.quant.ctypes.data,
-                     self.plane.data_ptr(), self.pitch, APRON_X, self.flags, self.luma, int(final_clamp))
+        self.smooth_rows(0, self.hblk, final_clamp)
+
+    def smooth_rows(self, row0, row1, final_clamp):
+        f = self.o.lib.qso_band_smooth_rows
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        f(self.coef.ctypes.data, self.wblk, self.hblk, self.quant.ctypes.data,
+          self.plane.data_ptr(), self.pitch, APRON_X, self.flags, self.luma, int(final_clamp), row0, row1)
 
     def row(self, y):
         o = self._row_off(y)

@@ -27,7 +27,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, flags, niter, tmp):
+def _worker(rank, world, port, flags, niter, tmp, overlapped=False):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
     import torch
     import torch.distributed as dist
@@ -44,21 +44,23 @@ def _worker(rank, world, port, flags, niter, tmp):
     r0, r1 = bands.band_rows(hblk, world, rank)
     topo = bands.BandTopology(rank, world, r0, r1)
     eng = OracleBandEngine(Oracle(), pkg.HipQS(), coef[r0:r1].copy(), quant, flags)
-    bands.run_band(eng, topo, niter, lambda: bands.exchange_halo_dist(eng, topo, dist))
+    runner = bands.run_band_overlapped if overlapped else bands.run_band
+    runner(eng, topo, niter, lambda: bands.exchange_halo_dist(eng, topo, dist))
     assert not eng.bad_coef()
     np.save(os.path.join(tmp, f"band{rank}.npy"), eng.coef)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,overlapped", [(2, False), (3, False), (2, True), (4, True)])
 @pytest.mark.parametrize("flags", [0, 1])
-def test_bands_gloo_equal_unsharded(world, flags, oracle, synth, tmp_path):
-    """world_size > 1, CPU, gloo: bands + halo exchange reproduce the unsharded result bit for bit"""
+def test_bands_gloo_equal_unsharded(world, overlapped, flags, oracle, synth, tmp_path):
+    """world_size > 1, CPU, gloo: bands + halo exchange reproduce the unsharded result
+    bit for bit, with the simple and with the communication-hiding schedule"""
     import torch.multiprocessing as mp
     niter = 3
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, flags, niter, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, flags, niter, str(tmp_path), overlapped), nprocs=world, join=True)
     coef, quant = synth.synth_gray(136, 200, 45, seed=21)
     want = oracle.do_quantsmooth([coef], [quant], flags, niter)["coefs"][0]
     got = np.concatenate([np.load(tmp_path / f"band{r}.npy") for r in range(world)], axis=0)
@@ -84,9 +86,18 @@ def test_bands_on_one_gpu_equal_unsharded(gpu, pkg, oracle, synth, nbands):
         for it in range(niter):
             for e, t in zip(engines, topos):
                 e.idct(it == 0, t.rep_top, t.rep_bot)
+            # interior rows first (they do not read the halo), then the exchange, then the edge rows:
+            # the order run_band_overlapped produces on a real multi-GPU run
+            for e, t in zip(engines, topos):
+                lo = 1 if t.up is not None else 0
+                hi = e.hblk - 1 if t.down is not None else e.hblk
+                e.smooth_rows(lo, hi, it == niter - 1)
             bands.exchange_halo_local(engines)
-            for e in engines:
-                e.smooth(it == niter - 1)
+            for e, t in zip(engines, topos):
+                if t.up is not None:
+                    e.smooth_rows(0, 1, it == niter - 1)
+                if t.down is not None:
+                    e.smooth_rows(e.hblk - 1, e.hblk, it == niter - 1)
         torch.cuda.synchronize()
         got = np.concatenate([e.coef.cpu().numpy() for e in engines], axis=0)
         want = oracle.do_quantsmooth([coef], [quant], flags, niter)["coefs"][0]
