@@ -145,6 +145,19 @@ extern "C" int qs_hip_consts_build(void* host_out, const uint16_t quant[64], int
   // exact only while no product underflows, which needs every non-zero weight
   // to be comfortably above 2^-38.  The tables are fixed functions of `flags`,
   // so this can only trip if the table construction itself is changed.
+  // The kernel skips the horizontal / vertical difference terms whose weight is
+  // structurally zero ((x+1)*u or (y+1)*v a multiple of 8, see qs_kernels.hip);
+  // that is only exact if the float tables really hold 0.0f there.
+  for (int k = 1; k < 64; ++k) {
+    const int i = kZigzag[k], u = i & 7, v = i >> 3;
+    const float* w = c->tab + (size_t)k * ts;
+    for (int y = 0; y < 8; ++y) for (int x = 0; x < 7; ++x)
+      if (u && ((x + 1) * u) % 8 == 0 && w[y * 8 + x] != 0.0f)
+        return fail(QS_HIP_EINVAL, "weight table: expected exact zero at k=%d h(%d,%d)", k, y, x);
+    for (int y = 0; y < 7; ++y) for (int x = 0; x < 8; ++x)
+      if (v && ((y + 1) * v) % 8 == 0 && w[96 + y * 8 + x] != 0.0f)
+        return fail(QS_HIP_EINVAL, "weight table: expected exact zero at k=%d v(%d,%d)", k, y, x);
+  }
   for (size_t j = 0; j < (size_t)64 * ts; ++j) {
     const float a = c->tab[j] < 0 ? -c->tab[j] : c->tab[j];
     if (a != 0.0f && a < 2.3283064e-10f /* 2^-32 */)

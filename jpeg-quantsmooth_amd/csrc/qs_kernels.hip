@@ -288,6 +288,13 @@ __device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
 #ifndef QS_PIN_DIFFS
 #define QS_PIN_DIFFS 1
 #endif
+// 1: specialise the H/V sections for u,v = 4; 2: also for u,v = 2,6 (see QS_HSEC).
+// Exact, and 4.6 / 7.7 % fewer terms at q3 -- but the extra wave-uniform branches
+// make hipcc spill 240-430 B/lane and the kernel runs 1.7x SLOWER (measured,
+// 4096^2: 0.92 vs 0.53 ms).  Off; a hand-scheduled kernel could take the win.
+#ifndef QS_SKIP_ZERO_WEIGHTS
+#define QS_SKIP_ZERO_WEIGHTS 0
+#endif
 // QS_PIN_EDGE=1 recomputes the 32 edge-pixel conversions at every anti-diagonal
 // (no scratch, HBM traffic close to algorithmic); 0 lets the compiler hoist them
 // out of the loop, where they end up in 124 B/lane of scratch.  Measured A/B on
@@ -544,20 +551,46 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
       const float* __restrict__ w = cst->tab + k * TS;
       float num = 0.0f, den = 0.0f;
 
+      // Structural zeros: for horizontal frequency u = i & 7 the weight
+      // T[p] - T[p+1] vanishes exactly whenever (x + 1) * u is a multiple of 8
+      // (the two cosines coincide): x = 1,3,5 for u = 4 and x = 3 for u = 2,6;
+      // same for the vertical differences with v = i >> 3.  A zero weight makes
+      // y = 0, so the term adds +0 to both sums -- skipping it is exact (the
+      // host verifies the table entries are 0.0f, qs_hip_consts_build).  That
+      // is 7.7 % of all terms at q3; the sections are specialised on a
+      // wave-uniform branch.
+#define QS_HSEC(MASK) { \
+        _Pragma("unroll") for (int y = 0; y < 8; ++y) \
+        _Pragma("unroll") for (int x = 0; x < 7; ++x) \
+          if (!(((MASK) >> x) & 1)) QS_TERM(px[y * 8 + x], px[y * 8 + x + 1], w[y * 8 + x]) }
+#define QS_VSEC(MASK) { \
+        _Pragma("unroll") for (int y = 0; y < 7; ++y) \
+        _Pragma("unroll") for (int x = 0; x < 8; ++x) \
+          if (!(((MASK) >> y) & 1)) QS_TERM(px[y * 8 + x], px[y * 8 + x + 8], w[96 + y * 8 + x]) }
       if (i & 7) {
-#pragma unroll
-        for (int y = 0; y < 8; ++y)
-#pragma unroll
-          for (int x = 0; x < 7; ++x) QS_TERM(px[y * 8 + x], px[y * 8 + x + 1], w[y * 8 + x])
+        const int u = i & 7;
+#if QS_SKIP_ZERO_WEIGHTS
+        if (u == 4) QS_HSEC(0x2a) else
+#if QS_SKIP_ZERO_WEIGHTS > 1
+        if ((u & 3) == 2) QS_HSEC(0x08) else
+#endif
+#endif
+        QS_HSEC(0)
       }
 #pragma unroll
       for (int j = 0; j < 32; ++j) QS_TERM_D(bd[j], w[64 + j])
       if (i > 7) {
-#pragma unroll
-        for (int y = 0; y < 7; ++y)
-#pragma unroll
-          for (int x = 0; x < 8; ++x) QS_TERM(px[y * 8 + x], px[y * 8 + x + 8], w[96 + y * 8 + x])
+        const int v = i >> 3;
+#if QS_SKIP_ZERO_WEIGHTS
+        if (v == 4) QS_VSEC(0x2a) else
+#if QS_SKIP_ZERO_WEIGHTS > 1
+        if ((v & 3) == 2) QS_VSEC(0x08) else
+#endif
+#endif
+        QS_VSEC(0)
       }
+#undef QS_HSEC
+#undef QS_VSEC
       if (DIAG) {
 #pragma unroll
         for (int y = 0; y < 7; ++y)
