@@ -288,12 +288,9 @@ __device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
 #ifndef QS_PIN_DIFFS
 #define QS_PIN_DIFFS 1
 #endif
-// 1: specialise the H/V sections for u,v = 4; 2: also for u,v = 2,6 (see QS_HSEC).
-// Exact, and 4.6 / 7.7 % fewer terms at q3 -- but the extra wave-uniform branches
-// make hipcc spill 240-430 B/lane and the kernel runs 1.7x SLOWER (measured,
-// 4096^2: 0.92 vs 0.53 ms).  Off; a hand-scheduled kernel could take the win.
+// skip the difference terms whose weight is structurally zero (see QS_TERM_OPT)
 #ifndef QS_SKIP_ZERO_WEIGHTS
-#define QS_SKIP_ZERO_WEIGHTS 0
+#define QS_SKIP_ZERO_WEIGHTS 1
 #endif
 // QS_PIN_EDGE=1 recomputes the 32 edge-pixel conversions at every anti-diagonal
 // (no scratch, HBM traffic close to algorithmic); 0 lets the compiler hoist them
@@ -553,44 +550,68 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
 
       // Structural zeros: for horizontal frequency u = i & 7 the weight
       // T[p] - T[p+1] vanishes exactly whenever (x + 1) * u is a multiple of 8
-      // (the two cosines coincide): x = 1,3,5 for u = 4 and x = 3 for u = 2,6;
-      // same for the vertical differences with v = i >> 3.  A zero weight makes
-      // y = 0, so the term adds +0 to both sums -- skipping it is exact (the
-      // host verifies the table entries are 0.0f, qs_hip_consts_build).  That
-      // is 7.7 % of all terms at q3; the sections are specialised on a
-      // wave-uniform branch.
-#define QS_HSEC(MASK) { \
-        _Pragma("unroll") for (int y = 0; y < 8; ++y) \
-        _Pragma("unroll") for (int x = 0; x < 7; ++x) \
-          if (!(((MASK) >> x) & 1)) QS_TERM(px[y * 8 + x], px[y * 8 + x + 1], w[y * 8 + x]) }
-#define QS_VSEC(MASK) { \
-        _Pragma("unroll") for (int y = 0; y < 7; ++y) \
-        _Pragma("unroll") for (int x = 0; x < 8; ++x) \
-          if (!(((MASK) >> y) & 1)) QS_TERM(px[y * 8 + x], px[y * 8 + x + 8], w[96 + y * 8 + x]) }
-      if (i & 7) {
-        const int u = i & 7;
+      // (the two cosines coincide): x = 1,3,5 for u = 4 and x = 3 for u = 2,4,6;
+      // same for the vertical differences with v = i >> 3 (whole rows y).  A zero
+      // weight makes y = 0, so the term adds +0 to both sums -- skipping it is
+      // exact (the host verifies the table entries are 0.0f,
+      // qs_hip_consts_build).  That is 7.7 % of all terms at q3.
+      // Mechanism: the 48 "optional" terms are emitted as inline-asm blocks that
+      // carry their own wave-uniform scalar test and branch, so the compiler
+      // sees straight-line code (branching in C++ made hipcc spill 240-430
+      // B/lane and run 1.7x slower).  skip4 = 1 when the frequency is 4, even = 1
+      // when it is 2, 4 or 6.
 #if QS_SKIP_ZERO_WEIGHTS
-        if (u == 4) QS_HSEC(0x2a) else
-#if QS_SKIP_ZERO_WEIGHTS > 1
-        if ((u & 3) == 2) QS_HSEC(0x08) else
+#define QS_TERM_OPT(COND, A, B, W) { float d_, t_; \
+        asm volatile( \
+          "s_cmp_lg_u32 %[c], 0\n\t" \
+          "s_cbranch_scc1 1f\n\t" \
+          "v_sub_f32 %[d], %[a], %[b]\n\t" \
+          "v_sub_f32 %[t], %[r], |%[d]| clamp\n\t" \
+          "v_mul_f32 %[t], %[t], %[t]\n\t" \
+          "v_mul_f32 %[d], %[d], %[t]\n\t" \
+          "v_mul_f32 %[t], %[w], %[t]\n\t" \
+          "v_mul_f32 %[d], %[d], %[t]\n\t" \
+          "v_add_f32 %[n], %[n], %[d]\n\t" \
+          "v_mul_f32 %[d], %[t], %[t]\n\t" \
+          "v_add_f32 %[e], %[e], %[d]\n" \
+          "1:" \
+          : [n] "+v"(num), [e] "+v"(den), [d] "=&v"(d_), [t] "=&v"(t_) \
+          : [a] "v"(A), [b] "v"(B), [w] "s"(W), [r] "s"(Rs), [c] "s"(COND) : "scc"); }
+#else
+#define QS_TERM_OPT(COND, A, B, W) QS_TERM(A, B, W)
 #endif
-#endif
-        QS_HSEC(0)
+      if (i & 7) {
+        const int u = __builtin_amdgcn_readfirstlane(i & 7);   // wave-uniform by construction
+        // plain bit arithmetic (a compare would be materialised in a VGPR, which the "s" operands reject)
+        const int skip4 = __builtin_amdgcn_readfirstlane((u >> 2) & (~u >> 1) & ~u & 1);
+        const int even = __builtin_amdgcn_readfirstlane(~u & 1);
+        (void)skip4; (void)even;
+#pragma unroll
+        for (int y = 0; y < 8; ++y)
+#pragma unroll
+          for (int x = 0; x < 7; ++x) {
+            if (x == 3) QS_TERM_OPT(even, px[y * 8 + x], px[y * 8 + x + 1], w[y * 8 + x])
+            else if (x & 1) QS_TERM_OPT(skip4, px[y * 8 + x], px[y * 8 + x + 1], w[y * 8 + x])
+            else QS_TERM(px[y * 8 + x], px[y * 8 + x + 1], w[y * 8 + x])
+          }
       }
 #pragma unroll
       for (int j = 0; j < 32; ++j) QS_TERM_D(bd[j], w[64 + j])
       if (i > 7) {
-        const int v = i >> 3;
-#if QS_SKIP_ZERO_WEIGHTS
-        if (v == 4) QS_VSEC(0x2a) else
-#if QS_SKIP_ZERO_WEIGHTS > 1
-        if ((v & 3) == 2) QS_VSEC(0x08) else
-#endif
-#endif
-        QS_VSEC(0)
+        const int v = __builtin_amdgcn_readfirstlane(i >> 3);
+        const int skip4 = __builtin_amdgcn_readfirstlane((v >> 2) & (~v >> 1) & ~v & 1);
+        const int even = __builtin_amdgcn_readfirstlane(~v & 1);
+        (void)skip4; (void)even;
+#pragma unroll
+        for (int y = 0; y < 7; ++y)
+#pragma unroll
+          for (int x = 0; x < 8; ++x) {
+            if (y == 3) QS_TERM_OPT(even, px[y * 8 + x], px[y * 8 + x + 8], w[96 + y * 8 + x])
+            else if (y & 1) QS_TERM_OPT(skip4, px[y * 8 + x], px[y * 8 + x + 8], w[96 + y * 8 + x])
+            else QS_TERM(px[y * 8 + x], px[y * 8 + x + 8], w[96 + y * 8 + x])
+          }
       }
-#undef QS_HSEC
-#undef QS_VSEC
+#undef QS_TERM_OPT
       if (DIAG) {
 #pragma unroll
         for (int y = 0; y < 7; ++y)
