@@ -293,13 +293,13 @@ __device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
 #define QS_SKIP_ZERO_WEIGHTS 1
 #endif
 // QS_PIN_EDGE=1 recomputes the 32 edge-pixel conversions at every anti-diagonal
-// (no scratch, HBM traffic close to algorithmic); 0 lets the compiler hoist them
-// out of the loop, where they end up in 124 B/lane of scratch.  Measured A/B on
-// MI355X (4096^2): 0 is 4 % faster at q3 and equal at q4 -- the kernel is
-// VALU-bound and the extra ~130 MB/launch of scratch traffic (<2 % of HBM peak)
-// is cheaper than 900 more VALU instructions per block.  Default: the fast one.
+// (no scratch: HBM traffic stays close to the algorithmic 256 B/block); 0 lets
+// the compiler hoist them out of the loop, where they end up in 124 B/lane of
+// scratch (+130 MB written and re-read per 8192^2 launch).  Measured A/B on
+// MI355X: 1 is 1 % faster at 8192^2 and 3 % slower at 4096^2 -- a wash in time,
+// so the variant without the spill traffic is the default.
 #ifndef QS_PIN_EDGE
-#define QS_PIN_EDGE 0
+#define QS_PIN_EDGE 1
 #endif
 // Explicit double-buffered scalar weight prefetch (QS_STEP below).  Measured on
 // MI355X: it makes 2-3 waves/SIMD as fast as 4, but at 4 waves/SIMD (the
