@@ -134,6 +134,13 @@ size_t qs_hip_upsample_bytes(int image_width, int image_height, int ws, int hs);
 int qs_hip_upsample_plane(const uint8_t *d_chroma, const uint8_t *d_luma_lowres, int cwblk,
 		const uint8_t *d_luma, int ywblk, int yhblk, uint8_t *d_pixels,
 		int image_width, int image_height, int ws, int hs, void *stream);
+/* the same with explicit geometry, for one band of a sharded image: w1 = chroma
+ * width in pixels (image level), h1 = valid low-res rows in this band, first_rows =
+ * how many of its leading rows belong to the image's first 8-row strip (they get
+ * the reference's right-edge replicate, :2390-2393), pitch = row pitch of d_pixels */
+int qs_hip_upsample_rows(const uint8_t *d_chroma, const uint8_t *d_luma_lowres, int cwblk,
+		const uint8_t *d_luma, int ywblk, int yhblk, uint8_t *d_pixels, size_t pitch,
+		int w1, int h1, int first_rows, int ws, int hs, void *stream);
 int qs_hip_fdct_plane(const uint8_t *d_pixels, size_t pitch, int16_t *d_coef, int wblk, int hblk, void *stream);
 
 /* final +-1023 clamp alone (reference :2668-2689) */

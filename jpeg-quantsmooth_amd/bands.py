@@ -201,3 +201,193 @@ class HipBandEngine(BandEngine):
             if join:
                 main.wait_stream(self._comm_stream)
         return begin, end
+
+
+# ---------------------------------------------------------------------------
+# YCbCr jobs with JOINT_YUV / UPSAMPLE_UV, sharded in row bands
+# (BASELINE config 4: 8192x8192 4:2:0, q=6, cross-component dependence)
+#
+# Chroma depends on the FINAL luma only (through the low-res luma plane L and,
+# for the upsample, the full-res luma plane; reference quantsmooth.h:2753-2815),
+# Cb and Cr are independent of each other.  Bands are cut on chroma block rows;
+# the luma band is the `vs`-times taller range of the same image rows, so the
+# downsample and the upsample of a band touch only that band's luma rows.  What
+# crosses a band edge: one pixel row of the component's own plane per
+# iteration (as in the luma-only case), one row of L once, and one row of the
+# refreshed chroma plane once (the 3x3 regression windows of the predictor and
+# of the upsample).
+
+class PlaneRows:
+    """row accessor over any plane-geometry tensor (for the halo exchange)"""
+
+    def __init__(self, hip, tensor, wblk, hblk):
+        self.hip, self.t, self.wblk, self.hblk = hip, tensor, wblk, hblk
+        self.pitch = hip.plane_pitch(wblk)
+
+    def row(self, y):
+        o = self.hip.plane_row_offset(self.wblk, y)
+        return self.t[o:o + self.pitch]
+
+
+class ColourBand:
+    """one rank's band of a 3-component YCbCr image, all buffers on the device"""
+
+    def __init__(self, hip, torch, coefs, quants, hsamp, vsamp, image_size, flags, niter, topo, device):
+        self.hip, self.torch, self.flags, self.niter, self.topo = hip, torch, flags, max(0, min(int(niter), 100)), topo
+        self.ws, self.hs = hsamp[0], vsamp[0]
+        self.image_w, self.image_h = image_size
+        self.dev = device
+        self.eng = [HipBandEngine(hip, torch, c, q, flags & 0x31, luma=int(ci == 0), device=device)
+                    for ci, (c, q) in enumerate(zip(coefs, quants))]
+        self.joint = bool(flags & 2)
+        self.upsample = bool(flags & 4) and (self.ws, self.hs) != (1, 1)
+        self.lowq = bool(flags & 8)
+        ce = self.eng[1]
+        self.L = None if (self.ws, self.hs) == (1, 1) else \
+            torch.zeros(hip.plane_bytes(ce.wblk, ce.hblk), dtype=torch.uint8, device=device)
+        self.up = [None, None]
+
+    # ---- helpers ---------------------------------------------------------
+    def _s(self):
+        return self.torch.cuda.current_stream().cuda_stream
+
+    def _rebalance(self, ci):
+        luma = ci == 0
+        return int(not (self.flags & 16) and (luma or not (self.flags & 32)))
+
+    def lowres_plane(self):
+        return self.eng[0].plane if self.L is None else self.L
+
+    def planes_for_halo(self, which):
+        e = self.eng[which] if isinstance(which, int) else None
+        if which == "L":
+            ce = self.eng[1]
+            return PlaneRows(self.hip, self.L, ce.wblk, ce.hblk)
+        return PlaneRows(self.hip, e.plane, e.wblk, e.hblk)
+
+    # ---- phases (the driver interleaves them with halo exchanges) ----------
+    def pass_a(self, ci, first):
+        self.eng[ci].idct(first, self.topo.rep_top, self.topo.rep_bot)
+
+    def pass_b(self, ci, last):
+        e = self.eng[ci]
+        s = self._s()
+        joint = ci > 0 and self.joint
+        if self.lowq:
+            if joint:
+                self.hip.joint_plane(e.cst.data_ptr(), e.coef.data_ptr(), e.plane.data_ptr(),
+                                     self.lowres_plane().data_ptr(), e.wblk, e.hblk, self._rebalance(ci), last, s)
+            else:
+                self.hip.lowq_plane(e.cst.data_ptr(), e.coef.data_ptr(), e.plane.data_ptr(), e.wblk, e.hblk,
+                                    self._rebalance(ci), last, s)
+            return
+        if joint:
+            self.hip.joint_plane(e.cst.data_ptr(), e.coef.data_ptr(), e.plane.data_ptr(),
+                                 self.lowres_plane().data_ptr(), e.wblk, e.hblk, 0, 0, s)
+        e.smooth(last)
+
+    def clamp(self, ci):
+        e = self.eng[ci]
+        self.hip.clamp_plane(e.coef.data_ptr(), e.wblk, e.hblk, self._s())
+
+    def downsample(self):
+        y, c = self.eng[0], self.eng[1]
+        self.hip.downsample_plane(y.plane.data_ptr(), y.wblk, y.hblk, self.L.data_ptr(), c.wblk, c.hblk,
+                                  self.ws, self.hs, self._s())
+
+    def upsample_chroma(self, ci, chroma_row0):
+        """chroma band -> coefficients at luma resolution (this band's luma rows)"""
+        torch, hip = self.torch, self.hip
+        y, c = self.eng[0], self.eng[ci]
+        w1 = (self.image_w + self.ws - 1) // self.ws
+        h1_img = (self.image_h + self.hs - 1) // self.hs
+        px0 = chroma_row0 * 8                                   # first low-res pixel row of the band (image coords)
+        h1 = max(0, min(h1_img - px0, c.hblk * 8))              # valid low-res rows inside the band
+        first_rows = max(0, min(8 - px0, h1))                   # rows of the image's first strip
+        pitch = hip.upsample_pitch(self.image_w, self.ws)
+        px = torch.zeros(pitch * (y.hblk * 8 + 8 * self.hs) + 64, dtype=torch.uint8, device=self.dev)
+        out = torch.zeros((y.hblk, y.wblk, 64), dtype=torch.int16, device=self.dev)
+        hip.upsample_rows(c.plane.data_ptr(), self.lowres_plane().data_ptr(), c.wblk, y.plane.data_ptr(),
+                          y.wblk, y.hblk, px.data_ptr(), pitch, w1, h1, first_rows, self.ws, self.hs, self._s())
+        hip.fdct_plane(px.data_ptr(), pitch, out.data_ptr(), y.wblk, y.hblk, self._s())
+        self.up[ci - 1] = out
+
+
+def run_colour_bands(bands, exchange) -> None:
+    """Drive one or more ColourBand objects through the whole job in lockstep.
+    `bands`: list of the bands living in this process (one per rank in a real
+    run, N logical bands in the single-GPU test); `exchange(rows_list)` swaps the
+    edge rows of the given PlaneRows (one per band) with the neighbours."""
+    b0 = bands[0]
+    niter, need_lowres = b0.niter, True
+    extra_y = 1
+    # ---- luma: iterations + the extra refresh that feeds the chroma passes
+    for it in range(niter + extra_y):
+        for b in bands:
+            b.pass_a(0, it == 0)
+        last_refresh = it == niter
+        if not last_refresh or b0.L is None:
+            exchange([b.planes_for_halo(0) for b in bands])    # 1x1 luma: L is this plane, its aprons are read
+        if last_refresh:
+            break
+        for b in bands:
+            b.pass_b(0, it == niter - 1)
+    if niter == 0:
+        for b in bands:
+            b.clamp(0)
+    if b0.L is not None:
+        for b in bands:
+            b.downsample()
+        exchange([b.planes_for_halo("L") for b in bands])
+    # ---- chroma
+    for ci in (1, 2):
+        extra = 1 if b0.upsample else 0
+        for it in range(niter + extra):
+            for b in bands:
+                b.pass_a(ci, it == 0)
+            exchange([b.planes_for_halo(ci) for b in bands])
+            if it == niter:
+                break
+            for b in bands:
+                b.pass_b(ci, it == niter - 1)
+        if niter == 0 and extra:
+            for b in bands:
+                b.clamp(ci)
+        if b0.upsample:
+            for b in bands:
+                b.upsample_chroma(ci, b.chroma_row0)
+
+
+def exchange_rows_local(rows_list) -> None:
+    for upper, lower in zip(rows_list[:-1], rows_list[1:]):
+        h = upper.hblk * 8
+        lower.row(-1).copy_(upper.row(h - 1))
+        upper.row(h).copy_(lower.row(0))
+
+
+def exchange_rows_dist(rows: PlaneRows, topo: BandTopology, dist) -> None:
+    ops = []
+    h = rows.hblk * 8
+    if topo.up is not None:
+        ops.append(dist.P2POp(dist.isend, rows.row(0), topo.up))
+        ops.append(dist.P2POp(dist.irecv, rows.row(-1), topo.up))
+    if topo.down is not None:
+        ops.append(dist.P2POp(dist.isend, rows.row(h - 1), topo.down))
+        ops.append(dist.P2POp(dist.irecv, rows.row(h), topo.down))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def colour_band_split(hblk_y, hblk_c, vs, world):
+    """[(luma r0, r1, chroma r0, r1)] per rank; cut on chroma block rows"""
+    out = []
+    for r in range(world):
+        c0, c1 = band_rows(hblk_c, world, r)
+        out.append((min(c0 * vs, hblk_y), min(c1 * vs, hblk_y), c0, c1))
+    return out
+
+
+def run_colour_band_dist(band: ColourBand, dist) -> None:
+    """one rank's share of a sharded YCbCr job (RCCL / gloo halo exchange)"""
+    run_colour_bands([band], lambda rows_list: exchange_rows_dist(rows_list[0], band.topo, dist))

@@ -269,15 +269,23 @@ extern "C" size_t qs_hip_upsample_bytes(int image_width, int image_height, int w
   return qs_hip_upsample_pitch(image_width, ws) * (size_t)(((h1 + 8) & -8) * hs) + 64;   // reference :2715-2716
 }
 
+extern "C" int qs_hip_upsample_rows(const uint8_t* d_chroma, const uint8_t* d_luma_lowres, int cwblk,
+                                    const uint8_t* d_luma, int ywblk, int yhblk, uint8_t* d_pixels, size_t pitch,
+                                    int w1, int h1, int first_rows, int ws, int hs, void* stream) {
+  if (int r = check_plane_args(d_chroma, d_luma, ywblk, yhblk, "qs_hip_upsample_rows")) return r;
+  if (!d_luma_lowres || !d_pixels || cwblk <= 0 || w1 <= 0 || h1 < 0 || first_rows < 0 || first_rows > h1)
+    return fail(QS_HIP_EINVAL, "qs_hip_upsample_rows: bad argument");
+  qs_launch_upsample(d_chroma, d_luma_lowres, cwblk, d_luma, ywblk, d_pixels, (int)pitch,
+                     ywblk * 8, yhblk * 8, w1, h1, first_rows, ws, hs, static_cast<hipStream_t>(stream));
+  return launch_status("qs_hip_upsample_rows");
+}
+
 extern "C" int qs_hip_upsample_plane(const uint8_t* d_chroma, const uint8_t* d_luma_lowres, int cwblk,
                                      const uint8_t* d_luma, int ywblk, int yhblk, uint8_t* d_pixels,
                                      int image_width, int image_height, int ws, int hs, void* stream) {
-  if (int r = check_plane_args(d_chroma, d_luma, ywblk, yhblk, "qs_hip_upsample_plane")) return r;
-  if (!d_luma_lowres || !d_pixels || cwblk <= 0) return fail(QS_HIP_EINVAL, "qs_hip_upsample_plane: null argument");
   const int w1 = (image_width + ws - 1) / ws, h1 = (image_height + hs - 1) / hs;
-  qs_launch_upsample(d_chroma, d_luma_lowres, cwblk, d_luma, ywblk, d_pixels, (int)qs_hip_upsample_pitch(image_width, ws),
-                     ywblk * 8, yhblk * 8, w1, h1, ws, hs, static_cast<hipStream_t>(stream));
-  return launch_status("qs_hip_upsample_plane");
+  return qs_hip_upsample_rows(d_chroma, d_luma_lowres, cwblk, d_luma, ywblk, yhblk, d_pixels,
+                              qs_hip_upsample_pitch(image_width, ws), w1, h1, h1 < 8 ? h1 : 8, ws, hs, stream);
 }
 
 extern "C" int qs_hip_fdct_plane(const uint8_t* d_pixels, size_t pitch, int16_t* d_coef, int wblk, int hblk, void* stream) {

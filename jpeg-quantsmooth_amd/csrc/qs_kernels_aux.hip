@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(256)
 qs_upsample_edges_kernel(uint8_t* __restrict__ out, int st, int ww, int hh, int w1, int h1, int ws, int hs, int phase) {
   const int x = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
   if (phase == 0) {
-    const int rows = min(8, h1) * hs;
+    const int rows = h1 * hs;          // h1 carries the number of first-strip rows here
     if (r >= rows || x < w1 * ws || x >= ww) return;
     out[(size_t)r * st + x] = out[(size_t)r * st + w1 * ws - 1];
   } else {
@@ -388,14 +388,17 @@ void qs_launch_downsample(const uint8_t* Y, int ywblk, int yhblk, uint8_t* L, in
 }
 
 void qs_launch_upsample(const uint8_t* C, const uint8_t* L, int cwblk, const uint8_t* Y, int ywblk,
-                        uint8_t* out, int st, int ww, int hh, int w1, int h1, int ws, int hs, hipStream_t s) {
+                        uint8_t* out, int st, int ww, int hh, int w1, int h1, int first_rows, int ws, int hs, hipStream_t s) {
+  // first_rows: how many leading low-res rows get the right-edge replicate
+  // (min(8, h1) for a whole image or the band that holds image row 0, else 0)
   const int xend = (w1 + 7) & ~7;
-  hipLaunchKernelGGL(qs_upsample_kernel, dim3((xend + 255) / 256, h1), dim3(256), 0, s,
-                     C, L, qs_plane_pitch(cwblk), Y, qs_plane_pitch(ywblk), out, st, xend, h1, ws, hs);
-  if (w1 * ws < ww)
-    hipLaunchKernelGGL(qs_upsample_edges_kernel, dim3((ww + 255) / 256, (h1 < 8 ? h1 : 8) * hs), dim3(256), 0, s,
-                       out, st, ww, hh, w1, h1, ws, hs, 0);
-  if (h1 * hs < hh)
+  if (h1 > 0)
+    hipLaunchKernelGGL(qs_upsample_kernel, dim3((xend + 255) / 256, h1), dim3(256), 0, s,
+                       C, L, qs_plane_pitch(cwblk), Y, qs_plane_pitch(ywblk), out, st, xend, h1, ws, hs);
+  if (w1 * ws < ww && first_rows > 0)
+    hipLaunchKernelGGL(qs_upsample_edges_kernel, dim3((ww + 255) / 256, first_rows * hs), dim3(256), 0, s,
+                       out, st, ww, hh, w1, first_rows, ws, hs, 0);
+  if (h1 * hs < hh && h1 > 0)
     hipLaunchKernelGGL(qs_upsample_edges_kernel, dim3((st + 255) / 256, hh - h1 * hs), dim3(256), 0, s,
                        out, st, ww, hh, w1, h1, ws, hs, 1);
 }

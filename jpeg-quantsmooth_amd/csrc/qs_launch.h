@@ -20,5 +20,5 @@ void qs_launch_lowq(const QsConsts* cst, int16_t* coef, const uint8_t* plane, in
 void qs_launch_downsample(const uint8_t* Y, int ywblk, int yhblk, uint8_t* L, int lwblk, int lhblk,
                           int ws, int hs, hipStream_t s);
 void qs_launch_upsample(const uint8_t* C, const uint8_t* L, int cwblk, const uint8_t* Y, int ywblk,
-                        uint8_t* out, int st, int ww, int hh, int w1, int h1, int ws, int hs, hipStream_t s);
+                        uint8_t* out, int st, int ww, int hh, int w1, int h1, int first_rows, int ws, int hs, hipStream_t s);
 void qs_launch_fdct_plane(const uint8_t* px, int st, int16_t* coef, int wblk, int hblk, hipStream_t s);

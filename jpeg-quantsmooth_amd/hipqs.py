@@ -89,6 +89,8 @@ ABI = {
     "qs_hip_upsample_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "qs_hip_upsample_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_upsample_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_fdct_plane": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_clamp_plane": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_dequant_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -225,6 +227,26 @@ class HipQS:
     def smooth_rows(self, d_consts, d_coef, d_plane, wblk, hblk, row0, row1, flags, luma=1, final_clamp=0, stream=None):
         self._check(self.lib.qs_hip_smooth_rows(d_consts, d_coef, d_plane, wblk, hblk, row0, row1, flags,
                                                 int(luma), int(final_clamp), stream))
+
+    def joint_plane(self, d_consts, d_coef, d_plane, d_lowres, wblk, hblk, rebalance=0, final_clamp=0, stream=None):
+        self._check(self.lib.qs_hip_joint_plane(d_consts, d_coef, d_plane, d_lowres, wblk, hblk,
+                                                int(rebalance), int(final_clamp), stream))
+
+    def lowq_plane(self, d_consts, d_coef, d_plane, wblk, hblk, rebalance=1, final_clamp=0, stream=None):
+        self._check(self.lib.qs_hip_lowq_plane(d_consts, d_coef, d_plane, wblk, hblk, int(rebalance), int(final_clamp), stream))
+
+    def downsample_plane(self, d_luma, ywblk, yhblk, d_lowres, lwblk, lhblk, ws, hs, stream=None):
+        self._check(self.lib.qs_hip_downsample_plane(d_luma, ywblk, yhblk, d_lowres, lwblk, lhblk, ws, hs, stream))
+
+    def upsample_pitch(self, image_width, ws):
+        return self.lib.qs_hip_upsample_pitch(image_width, ws)
+
+    def upsample_rows(self, d_chroma, d_lowres, cwblk, d_luma, ywblk, yhblk, d_pixels, pitch, w1, h1, first_rows, ws, hs, stream=None):
+        self._check(self.lib.qs_hip_upsample_rows(d_chroma, d_lowres, cwblk, d_luma, ywblk, yhblk, d_pixels, pitch,
+                                                  w1, h1, first_rows, ws, hs, stream))
+
+    def fdct_plane(self, d_pixels, pitch, d_coef, wblk, hblk, stream=None):
+        self._check(self.lib.qs_hip_fdct_plane(d_pixels, pitch, d_coef, wblk, hblk, stream))
 
     def clamp_plane(self, d_coef, wblk, hblk, stream=None):
         self._check(self.lib.qs_hip_clamp_plane(d_coef, wblk, hblk, stream))

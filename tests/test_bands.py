@@ -102,3 +102,74 @@ def test_bands_on_one_gpu_equal_unsharded(gpu, pkg, oracle, synth, nbands):
         got = np.concatenate([e.coef.cpu().numpy() for e in engines], axis=0)
         want = oracle.do_quantsmooth([coef], [quant], flags, niter)["coefs"][0]
         assert np.array_equal(got, want), f"flags={flags}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,samp,nbands", [((256, 160), (2, 2), 2), ((333, 517), (2, 2), 3), ((321, 200), (2, 2), 2),
+                                               ((160, 96), (1, 1), 2), ((208, 128), (2, 1), 2)])
+def test_colour_bands_on_one_gpu_equal_unsharded(gpu, pkg, oracle, synth, size, samp, nbands):
+    """BASELINE config 4 shape (YCbCr, JOINT_YUV + UPSAMPLE_UV) cut into N logical
+    bands on one device: luma/chroma halos per iteration, one-time halo of the
+    low-res luma and of the refreshed chroma, band-local downsample / upsample /
+    re-FDCT -- bit-exact against the unsharded oracle"""
+    import torch
+    from jpeg_quantsmooth_amd import bands as B
+    w, h = size
+    hs_, vs_ = samp
+    j = synth.synth_ycc(w, h, hs_, vs_, quality=40, seed=12)
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(w, h))
+    dev = torch.device("cuda:0")
+    hby, hbc = j["hblk"][0], j["hblk"][1]
+    split = B.colour_band_split(hby, hbc, vs_, nbands)
+    for flags, niter in ((7, 2), (3, 2), (7, 0), (7 | 32, 1), (15, 2), (5, 1)):
+        bl = []
+        for r, (y0, y1, c0, c1) in enumerate(split):
+            topo = B.BandTopology(r, nbands, c0, c1)
+            coefs = [torch.from_numpy(j["coefs"][0][y0:y1].copy()).to(dev),
+                     torch.from_numpy(j["coefs"][1][c0:c1].copy()).to(dev),
+                     torch.from_numpy(j["coefs"][2][c0:c1].copy()).to(dev)]
+            b = B.ColourBand(gpu, torch, coefs, j["quants"], j["hsamp"], j["vsamp"], (w, h), flags, niter, topo, dev)
+            b.chroma_row0 = c0
+            bl.append(b)
+        B.run_colour_bands(bl, B.exchange_rows_local)
+        torch.cuda.synchronize()
+        want = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+        gotY = np.concatenate([b.eng[0].coef.cpu().numpy() for b in bl], axis=0)
+        assert np.array_equal(gotY, want["coefs"][0]), f"Y flags={flags} niter={niter}"
+        for ci in (1, 2):
+            if want["up"]:
+                got = np.concatenate([b.up[ci - 1].cpu().numpy() for b in bl], axis=0)
+            else:
+                got = np.concatenate([b.eng[ci].coef.cpu().numpy() for b in bl], axis=0)
+            assert got.shape == want["coefs"][ci].shape, (got.shape, want["coefs"][ci].shape)
+            assert np.array_equal(got, want["coefs"][ci]), f"comp {ci} flags={flags} niter={niter}"
+
+
+def _rows_worker(rank, world, port, tmp):
+    sys.path.insert(0, str(ROOT))
+    import torch
+    import torch.distributed as dist
+    import jpegqs_pkg
+    pkg = jpegqs_pkg.load()
+    from jpeg_quantsmooth_amd import bands as B
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hip = pkg.HipQS()
+    wblk, hblk = 5, 2 + rank
+    t = torch.full((hip.plane_bytes(wblk, hblk),), 100 + rank, dtype=torch.uint8)
+    rows = B.PlaneRows(hip, t, wblk, hblk)
+    rows.row(0)[:] = 10 + rank            # first pixel row
+    rows.row(hblk * 8 - 1)[:] = 50 + rank   # last pixel row
+    topo = B.BandTopology(rank, world, 0, hblk)
+    B.exchange_rows_dist(rows, topo, dist)
+    top, bot = int(rows.row(-1)[20]), int(rows.row(hblk * 8)[20])
+    exp_top = 50 + rank - 1 if rank > 0 else 100 + rank          # neighbour's last row, or untouched
+    exp_bot = 10 + rank + 1 if rank < world - 1 else 100 + rank
+    assert (top, bot) == (exp_top, exp_bot), (rank, top, bot)
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_plane_rows_exchange_gloo(tmp_path):
+    """the generic row exchange used by the colour band driver, world_size 3, bands of unequal height"""
+    import torch.multiprocessing as mp
+    mp.spawn(_rows_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
