@@ -109,6 +109,19 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 		}
 	}
 
+	/* reference :2569-2572 prints this when it starts on a component's plane:
+	 * every component with a table whose values are not all <= 1, unless the
+	 * iteration count leaves it nothing to do */
+	if (flags & JPEGQS_INFO_COMP2)
+		for (ci = 0; ci < job.ncomp; ci++) {
+			int acc = 0;
+			if (!job.has_quant[ci]) continue;
+			for (i = 0; i < DCTSIZE2; i++) acc |= job.quant[ci][i];
+			if (acc >= 0x800) break;                     /* rejected table: the reference stops here */
+			if (acc <= 1 || opts->niter <= 0) continue;
+			logfmt("component[%i] : size %ix%i\n", ci, job.wblk[ci], job.hblk[ci]);
+		}
+
 	ret = qs_hip_do_quantsmooth(&job, flags & JPEGQS_FLAGS_MASK, opts->niter, opts->progprec,
 			opts->progress, opts->userdata);
 	if (ret < 0) {

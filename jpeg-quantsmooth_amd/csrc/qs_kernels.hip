@@ -14,11 +14,17 @@
 // quantiser data and control flow are wave-uniform (scalar loads + uniform
 // branches) and nothing diverges.
 //
-// Per-lane state: the block's 64 pixels and 32 neighbour-edge pixels live in
-// VGPRs as exact small floats (pixel differences are then one v_sub_f32); the
-// 64 int16 coefficients live in LDS, one dword column per lane (stride 65
-// dwords => conflict-free both for the per-lane column accesses and for the
-// coalesced-load transpose).
+// Per-lane state: the block's 64 pixels (scaled by 2^-12, see QS_TERM_D) and the
+// 32 edge differences live in VGPRs as exact small floats, so an interior pixel
+// difference is one v_sub_f32; the 32 neighbour-edge pixels stay packed four to
+// a VGPR; the 64 int16 coefficients live in LDS, one dword column per lane
+// (stride 65 dwords => conflict-free both for the per-lane column accesses and
+// for the coalesced-load transpose).  128 VGPRs => 4 waves per SIMD.
+//
+// Build-time switches (all default to the measured-best setting; the others are
+// kept as checked-in experiments): QS_SMOOTH_MIN_WAVES,
+// QS_PIN_DIFFS, QS_PIN_EDGE, QS_SKIP_ZERO_WEIGHTS, QS_SMEM_PIPELINE,
+// QS_IDCT_DOT2, QS_ABLATE_*.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "qs_device.h"
@@ -330,20 +336,26 @@ typedef float qs_w16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >> (8 * n)) & 0xffu); }
 
+// waves per workgroup: the waves of a workgroup share nothing (each has its own
+// LDS slice), so the size only sets the dispatch granularity
+#ifndef QS_WAVES_PER_WG
+#define QS_WAVES_PER_WG 4
+#endif
+
 template <bool DIAG>
-__global__ void __launch_bounds__(256, QS_SMOOTH_MIN_WAVES)
+__global__ void __launch_bounds__(64 * QS_WAVES_PER_WG, QS_SMOOTH_MIN_WAVES)
 qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
                        const uint8_t* __restrict__ plane, int wblk, int hblk, int pitch,
                        int rebalance, int final_clamp, int blk_begin, int blk_end) {
   // blocks [blk_begin, blk_end) of the plane (linear, row-major): the whole
   // plane, or the interior / the edge block rows of a band when the halo
   // exchange is overlapped with the interior (bands.py)
-  __shared__ uint32_t lds_all[4][32 * QS_LDS_PITCH];
+  __shared__ uint32_t lds_all[QS_WAVES_PER_WG][32 * QS_LDS_PITCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t* lds = lds_all[wave];
   uint32_t* col = lds + lane;
   const int nblk = blk_end;
-  const int base = blk_begin + (blockIdx.x * 4 + wave) * 64;
+  const int base = blk_begin + (blockIdx.x * QS_WAVES_PER_WG + wave) * 64;
   if (base >= nblk) return;  // wave-uniform
   const int nvec = min(64, nblk - base) * 8;
 
@@ -774,7 +786,8 @@ void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* p
                             int diag, int rebalance, int final_clamp, int blk_begin, int blk_end, hipStream_t s) {
   const int n = blk_end - blk_begin;
   if (n <= 0) return;
-  const dim3 grid((n + 255) / 256), block(256);
+  const int per_wg = 64 * QS_WAVES_PER_WG;
+  const dim3 grid((n + per_wg - 1) / per_wg), block(per_wg);
   if (diag)
     hipLaunchKernelGGL(qs_smooth_plane_kernel<true>, grid, block, 0, s,
                        cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), rebalance, final_clamp, blk_begin, blk_end);

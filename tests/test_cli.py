@@ -99,3 +99,22 @@ def test_decode_mode_matches_reference_pixels(gpu, src, quality, niter):
     r = subprocess.run([str(DECODE), str(quality), str(niter), str(GOLD / f"{src}.jpg")], capture_output=True)
     assert r.returncode == 0, r.stderr.decode()
     assert r.stdout == (GOLD / f"{src}.q{quality}.dec.ref.raw").read_bytes()
+
+
+@pytest.mark.gpu
+def test_cli_info_output_matches_reference(gpu, tmp_path):
+    """default --info 15: component table, quantisation tables, plane sizes and the
+    timing line, as the reference prints them (reference quantsmooth.h:2422-2445,
+    2569-2572, 2820-2825); only the measured time differs"""
+    _need_cli()
+    r = subprocess.run([str(CLI), "-q", "3", "-n", "1", str(GOLD / "rgb141x93_420.jpg"), str(tmp_path / "o.jpg")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0
+    want = (GOLD / "rgb141x93_420.q3.info.ref.txt").read_text().splitlines()
+    got = [l for l in r.stderr.splitlines() if "amdgpu.ids" not in l]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        if w.startswith("quantsmooth:"):
+            assert g.startswith("quantsmooth: ") and g.endswith("ms")
+        else:
+            assert g == w
