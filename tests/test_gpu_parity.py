@@ -222,3 +222,29 @@ def test_gpu_max_plane_16384(gpu, synth):
     g = eng.coef.to(torch.int32)
     assert int(g.abs().max()) <= 1023
     assert bool((((g - deq).abs() <= q // 2) | (g.abs() == 1023)).all())
+
+
+def test_gpu_job_layer_is_thread_safe(gpu, oracle, synth):
+    """concurrent do_quantsmooth() calls from host threads (a serving process):
+    each call leases its own streams and pooled device buffers; results stay bit-exact"""
+    import threading
+    j = synth.synth_ycc(320, 200, 2, 2, quality=50, seed=31)
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(320, 200))
+    want = {fl: oracle.do_quantsmooth(j["coefs"], j["quants"], fl, 2, **kw) for fl in (0, 7)}
+    errors = []
+
+    def worker(t):
+        try:
+            for n in range(6):
+                fl = (0, 7)[(t + n) & 1]
+                got = gpu.do_quantsmooth(j["coefs"], j["quants"], fl, 2, **kw)
+                assert_same_result(got, want[fl], f"thread {t} job {n} flags={fl}")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    gpu.lib.qs_hip_release_cache()
