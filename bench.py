@@ -57,7 +57,9 @@ def parse_args():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange halos between the passes instead of behind the interior rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="CPU baseline sample is NxN pixels")
-    ap.add_argument("--verify", action="store_true", help="check a band against the oracle after the run")
+    ap.add_argument("--verify", action="store_true", help="check rows against the oracle after the run (N > 1: rows around every band edge)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="torch.distributed backend (gloo: functional test of the sharded path)")
+    ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (functional test of the sharded path on a 1-GPU box, with --backend gloo)")
     return ap.parse_args()
 
 
@@ -135,10 +137,15 @@ def main():
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE={world})", file=sys.stderr)
             sys.exit(2)
         args.gpus = world
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = jpegqs_pkg.load()
     hip = pkg.HipQS()          # raises if the HIP library is missing: no fallback
@@ -162,6 +169,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_sample = full.cpu().numpy()
     band_for_verify = full[: min(16, hblk_total)].contiguous().cpu().numpy() if (args.verify and rank == 0) else None
+    edge_checks = []
+    if args.verify and world > 1 and not args.weak:
+        # the two block rows on our side of each band edge, checked against the oracle run on a
+        # crop around the edge (a block after n iterations depends only on blocks within n of it)
+        m = args.niter + 2
+        for edge, mine in [e for e in ((r1, (r1 - 2, r1)) if topo.down is not None else None,
+                                       (r0, (r0, r0 + 2)) if topo.up is not None else None) if e]:
+            lo, hi = max(0, edge - 2 - m), min(hblk_total, edge + 2 + m)
+            edge_checks.append((lo, mine, full[lo:hi].contiguous().cpu().numpy()))
     del full
 
     nsteps = args.steps + args.warmup
@@ -172,6 +188,7 @@ def main():
     sharded = topo.up is not None or topo.down is not None
 
     comm = eng.comm_scope() if sharded else None
+    exch = bands.exchange_halo_dist if args.backend == "nccl" else bands.exchange_halo_dist_hostcopy
 
     def step(coef, timed):
         eng.rebind(coef)
@@ -179,10 +196,9 @@ def main():
             # interior rows run while the halo rows travel (bands.run_band_overlapped);
             # per-kernel event timing is an N = 1 matter (roofline is reported there)
             if args.no_overlap:
-                bands.run_band(eng, topo, args.niter, lambda: bands.exchange_halo_dist(eng, topo, dist))
+                bands.run_band(eng, topo, args.niter, lambda: exch(eng, topo, dist))
             else:
-                bands.run_band_overlapped(eng, topo, args.niter,
-                                          lambda: bands.exchange_halo_dist(eng, topo, dist), comm=comm)
+                bands.run_band_overlapped(eng, topo, args.niter, lambda: exch(eng, topo, dist), comm=comm)
             return
         for it in range(args.niter):
             eng.idct(it == 0, topo.rep_top, topo.rep_bot)
@@ -209,9 +225,20 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    edges_ok = None
+    if args.verify and world > 1 and not args.weak:
+        from oracle.oracle import Oracle
+        got = work[-1].cpu().numpy()                      # the last step's result, this rank's band
+        ok = True
+        for lo, (a0, a1), crop in edge_checks:
+            want = Oracle().do_quantsmooth([crop], [quant], flags, args.niter, threads=0)["coefs"][0]
+            ok &= bool(np.array_equal(got[a0 - r0:a1 - r0], want[a0 - lo:a1 - lo]))
+        flag = torch.tensor([int(ok)], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        edges_ok = bool(flag.item())
     assert not eng.bad_coef(), "range check tripped on synthetic input"
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
@@ -255,6 +282,8 @@ def main():
         if cpu_sample is not None:
             out["cpu_baseline"] = cpu_baseline(pkg, args, cpu_sample, quant, flags)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if edges_ok is not None:
+            out["verify_band_edges_ok"] = edges_ok
         if band_for_verify is not None:
             from oracle.oracle import Oracle
             n = band_for_verify.shape[0]

@@ -88,6 +88,28 @@ def exchange_halo_dist(engine: BandEngine, topo: BandTopology, dist) -> None:
             w.wait()
 
 
+def exchange_halo_dist_hostcopy(engine: BandEngine, topo: BandTopology, dist) -> None:
+    """the same exchange staged through host memory: for back ends without
+    device-buffer p2p (gloo), i.e. functional tests of the multi-process path
+    on a box where RCCL cannot run (one GPU)"""
+    import torch
+    h = engine.hblk * 8
+    ops, recvs = [], []
+    for nbr, src_y, dst_y in ((topo.up, 0, -1), (topo.down, h - 1, h)):
+        if nbr is None:
+            continue
+        out = engine.row(src_y).to("cpu")               # stream-ordered after pass A (blocking copy)
+        buf = torch.empty_like(out)
+        ops.append(dist.P2POp(dist.isend, out, nbr))
+        ops.append(dist.P2POp(dist.irecv, buf, nbr))
+        recvs.append((dst_y, buf))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for dst_y, buf in recvs:
+        engine.row(dst_y).copy_(buf)
+
+
 def exchange_halo_local(engines) -> None:
     """the same exchange between N logical bands living in one process
     (device-to-device copies): used to test the band logic on a single GPU"""

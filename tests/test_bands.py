@@ -173,3 +173,24 @@ def test_plane_rows_exchange_gloo(tmp_path):
     """the generic row exchange used by the colour band driver, world_size 3, bands of unequal height"""
     import torch.multiprocessing as mp
     mp.spawn(_rows_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--no-overlap"]])
+def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one
+    process per rank, band split, comm side stream, overlapped schedule), but on ONE
+    GPU with the gloo back end and host-staged halo rows; the rows on both sides of
+    the band edge are checked against the oracle inside bench.py (--verify)"""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+           "--size", "1024", "--steps", "2", "--warmup", "1", "--verify", "--no-cpu-baseline", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["verify_band_edges_ok"] is True and d["verify_ok"] is True
