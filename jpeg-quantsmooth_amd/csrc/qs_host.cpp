@@ -15,10 +15,15 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdarg.h>
+#include <stddef.h>
 #include <math.h>
 #include <new>
 #include <mutex>
 #include <vector>
+#include <atomic>
+#include <thread>
+#include <algorithm>
+#include <chrono>
 
 #include "../../include/jpegqs_hip.h"
 #include "qs_device.h"
@@ -100,30 +105,23 @@ static void impulse_response(int i, float T[64]) {
   for (int y = 0; y < 8; ++y) idct8f(ws + y * 8, 1, T + y * 8, 1, true); // rows
 }
 
-extern "C" int qs_hip_consts_build(void* host_out, const uint16_t quant[64], int flags) {
-  if (!host_out || !quant) return fail(QS_HIP_EINVAL, "qs_hip_consts_build: null argument");
-  QsConsts* c = static_cast<QsConsts*>(host_out);
-  memset(c, 0, sizeof(*c));
-  const bool diag = (flags & QS_DIAGONALS) != 0;
+// The weight tables depend only on the DIAGONALS flag: built (and checked) once
+// per process, copied into every component's constant block.
+struct WeightTables {
+  float tab[2][64 * QS_TAB_MAX];
+  int status[2];
+  char msg[2][160];
+};
+
+static void build_tables(WeightTables& W, int diag) {
   const int ts = diag ? 272 : 160;
   const float b = diag ? 4.0f : 2.0f;
-  c->tab_size = ts;
-  int qn[64], x1n[64], x2n[64];
-  for (int i = 0; i < 64; ++i) {           // reference :2506-2539
-    unsigned q = quant[i] ? quant[i] : 1u, n = 0, t = q;
-    while (t > 1) { t >>= 1; ++n; }
-    unsigned x1 = ((0x10000u << n) + q - 1) / q;
-    if (n) x1 |= x1 >> 16;
-    int x2 = -0x8000 >> n;
-    qn[i] = (int)q; x1n[i] = (int16_t)(uint16_t)x1; x2n[i] = (int16_t)(uint16_t)x2;
-    c->qraw[i] = quant[i];
-    c->qn[i] = qn[i]; c->x1n[i] = x1n[i]; c->x2n[i] = x2n[i];
-  }
+  float* tab = W.tab[diag];
+  memset(tab, 0, sizeof(W.tab[diag]));
+  W.status[diag] = QS_HIP_OK;
   for (int k = 0; k < 64; ++k) {
     const int i = kZigzag[k];
-    c->nat[k] = i; c->q[k] = qn[i]; c->x1[k] = x1n[i]; c->x2[k] = x2n[i];
-    c->range[k] = (float)(qn[i] * 2) * 0.000244140625f;  // R * 2^-12, see QS_TERM_D
-    float T[64], *w = c->tab + (size_t)k * ts;   // reference :251-301, layout in SURVEY A.4
+    float T[64], *w = tab + (size_t)k * ts;      // reference :251-301, layout in SURVEY A.4
     impulse_response(i, T);
     for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) {
       const int p = y * 8 + x;
@@ -141,28 +139,71 @@ extern "C" int qs_hip_consts_build(void* host_out, const uint16_t quant[64], int
         w[168 + 16 * y + x] = x < 7 ? T[p + 1] - T[p + 8] : 0.0f;
       }
   }
-  // The kernel evaluates the sums in a 2^-k scaled domain (QS_TERM_D); that is
-  // exact only while no product underflows, which needs every non-zero weight
-  // to be comfortably above 2^-38.  The tables are fixed functions of `flags`,
-  // so this can only trip if the table construction itself is changed.
   // The kernel skips the horizontal / vertical difference terms whose weight is
   // structurally zero ((x+1)*u or (y+1)*v a multiple of 8, see qs_kernels.hip);
   // that is only exact if the float tables really hold 0.0f there.
   for (int k = 1; k < 64; ++k) {
     const int i = kZigzag[k], u = i & 7, v = i >> 3;
-    const float* w = c->tab + (size_t)k * ts;
+    const float* w = tab + (size_t)k * ts;
     for (int y = 0; y < 8; ++y) for (int x = 0; x < 7; ++x)
-      if (u && ((x + 1) * u) % 8 == 0 && w[y * 8 + x] != 0.0f)
-        return fail(QS_HIP_EINVAL, "weight table: expected exact zero at k=%d h(%d,%d)", k, y, x);
+      if (u && ((x + 1) * u) % 8 == 0 && w[y * 8 + x] != 0.0f) {
+        W.status[diag] = QS_HIP_EINVAL;
+        snprintf(W.msg[diag], sizeof(W.msg[diag]), "weight table: expected exact zero at k=%d h(%d,%d)", k, y, x);
+      }
     for (int y = 0; y < 7; ++y) for (int x = 0; x < 8; ++x)
-      if (v && ((y + 1) * v) % 8 == 0 && w[96 + y * 8 + x] != 0.0f)
-        return fail(QS_HIP_EINVAL, "weight table: expected exact zero at k=%d v(%d,%d)", k, y, x);
+      if (v && ((y + 1) * v) % 8 == 0 && w[96 + y * 8 + x] != 0.0f) {
+        W.status[diag] = QS_HIP_EINVAL;
+        snprintf(W.msg[diag], sizeof(W.msg[diag]), "weight table: expected exact zero at k=%d v(%d,%d)", k, y, x);
+      }
   }
+  // The kernel evaluates the sums in a 2^-k scaled domain (QS_TERM_D); that is
+  // exact only while no product underflows, which needs every non-zero weight
+  // to be comfortably above 2^-38.
   for (size_t j = 0; j < (size_t)64 * ts; ++j) {
-    const float a = c->tab[j] < 0 ? -c->tab[j] : c->tab[j];
-    if (a != 0.0f && a < 2.3283064e-10f /* 2^-32 */)
-      return fail(QS_HIP_EINVAL, "weight table entry %g too small for the scaled evaluation", (double)a);
+    const float a = tab[j] < 0 ? -tab[j] : tab[j];
+    if (a != 0.0f && a < 2.3283064e-10f /* 2^-32 */) {
+      W.status[diag] = QS_HIP_EINVAL;
+      snprintf(W.msg[diag], sizeof(W.msg[diag]), "weight table entry %g too small for the scaled evaluation", (double)a);
+    }
   }
+}
+
+static const WeightTables& weight_tables() {
+  static WeightTables* W = [] {
+    WeightTables* w = new WeightTables;
+    build_tables(*w, 0);
+    build_tables(*w, 1);
+    return w;
+  }();
+  return *W;
+}
+
+extern "C" int qs_hip_consts_build(void* host_out, const uint16_t quant[64], int flags) {
+  if (!host_out || !quant) return fail(QS_HIP_EINVAL, "qs_hip_consts_build: null argument");
+  QsConsts* c = static_cast<QsConsts*>(host_out);
+  const int diag = (flags & QS_DIAGONALS) != 0;
+  const int ts = diag ? 272 : 160;
+  const WeightTables& W = weight_tables();
+  if (W.status[diag] != QS_HIP_OK) return fail(W.status[diag], "%s", W.msg[diag]);
+  memset(c, 0, offsetof(QsConsts, tab));
+  c->tab_size = ts;
+  int qn[64], x1n[64], x2n[64];
+  for (int i = 0; i < 64; ++i) {           // reference :2506-2539
+    unsigned q = quant[i] ? quant[i] : 1u, n = 0, t = q;
+    while (t > 1) { t >>= 1; ++n; }
+    unsigned x1 = ((0x10000u << n) + q - 1) / q;
+    if (n) x1 |= x1 >> 16;
+    int x2 = -0x8000 >> n;
+    qn[i] = (int)q; x1n[i] = (int16_t)(uint16_t)x1; x2n[i] = (int16_t)(uint16_t)x2;
+    c->qraw[i] = quant[i];
+    c->qn[i] = qn[i]; c->x1n[i] = x1n[i]; c->x2n[i] = x2n[i];
+  }
+  for (int k = 0; k < 64; ++k) {
+    const int i = kZigzag[k];
+    c->nat[k] = i; c->q[k] = qn[i]; c->x1[k] = x1n[i]; c->x2[k] = x2n[i];
+    c->range[k] = (float)(qn[i] * 2) * 0.000244140625f;  // R * 2^-12, see QS_TERM_D
+  }
+  memcpy(c->tab, W.tab[diag], sizeof(c->tab));
   return QS_HIP_OK;
 }
 
@@ -364,6 +405,75 @@ struct DevBuf {
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// ---- host -> device upload of large pageable buffers -------------------------
+// Measured on the MI355X box (tools/ubench_pcie.hip, 128 MiB): pageable
+// hipMemcpy H2D 17-19 GB/s, pinned 57 GB/s, hipHostRegister 6 ms + 57 GB/s,
+// memcpy into pinned memory 30 GB/s with one thread and 60-90 GB/s with 4-8;
+// pageable D2H already runs at 55 GB/s.  So uploads above a few MiB go through a
+// pooled pinned staging buffer: four threads copy 8 MiB chunks into it and each
+// chunk's DMA is queued as soon as it is complete, overlapping the next copy.
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t n = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() { release(); }
+  static std::vector<CacheEntry>& pool() { static std::vector<CacheEntry> v; return v; }
+  bool alloc(size_t bytes) {
+    const size_t want = round_size(bytes);
+    {
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      auto& v = pool();
+      for (size_t i = 0; i < v.size(); ++i)
+        if (v[i].n == want) { p = v[i].p; n = want; v.erase(v.begin() + i); return true; }
+    }
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+    n = want;
+    return true;
+  }
+  void release() {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    size_t held = 0;
+    for (auto& c : pool()) held += c.n;
+    if (held + n <= ((size_t)2 << 30)) pool().push_back({p, n}); else (void)hipHostFree(p);
+    p = nullptr; n = 0;
+  }
+};
+
+static const size_t kStageMin = (size_t)4 << 20, kStageChunk = (size_t)8 << 20;
+static const int kStageThreads = 4;
+
+// copy `bytes` from pageable `src` to device `dst` on `s`; `stage` must outlive the stream work
+static hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t s, PinnedBuf& stage) {
+  if (bytes < kStageMin || !stage.alloc(bytes))
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+  const size_t nchunks = (bytes + kStageChunk - 1) / kStageChunk;
+  std::vector<std::atomic<int>> done(nchunks);
+  for (auto& d : done) d.store(0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < kStageThreads; ++t)
+    th.emplace_back([&, t] {
+      for (size_t c = 0; c < nchunks; ++c) {
+        const size_t c0 = c * kStageChunk, clen = std::min(kStageChunk, bytes - c0);
+        const size_t part = (clen / kStageThreads + 63) & ~(size_t)63;
+        const size_t o = std::min(clen, (size_t)t * part), e = std::min(clen, o + part);
+        if (e > o) memcpy(static_cast<char*>(stage.p) + c0 + o, static_cast<const char*>(src) + c0 + o, e - o);
+        done[c].fetch_add(1, std::memory_order_release);
+      }
+    });
+  hipError_t err = hipSuccess;
+  for (size_t c = 0; c < nchunks; ++c) {
+    while (done[c].load(std::memory_order_acquire) < kStageThreads) std::this_thread::yield();
+    const size_t c0 = c * kStageChunk, clen = std::min(kStageChunk, bytes - c0);
+    if (err == hipSuccess)
+      err = hipMemcpyAsync(static_cast<char*>(dst) + c0, static_cast<char*>(stage.p) + c0, clen, hipMemcpyHostToDevice, s);
+  }
+  for (auto& x : th) x.join();
+  return err;
+}
+
 struct Streams {
   hipStream_t s[3] = {nullptr, nullptr, nullptr};
   hipEvent_t luma_done = nullptr;
@@ -400,11 +510,17 @@ struct StreamLease {     // borrow a ready-made set of streams, give it back on 
 
 struct Comp {            // per-component device state (kept until the job ends)
   DevBuf coef, plane, cst, status, up, px;
+  PinnedBuf stage;           // pinned upload staging, held until the job's streams are drained
   bool processed = false, dequant_only = false, have_up = false;
   hipStream_t stream = nullptr;
 };
 
 enum { JOB_RERUN_CAREFUL = -1000 };
+
+static double wall_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static bool trace_on() { static const bool on = getenv("QS_HIP_TRACE") != nullptr; return on; }
 
 static int run_job(qs_hip_job* job, int flags, int niter, int progprec,
                    qs_hip_progress_fn progress, void* userdata, bool eager) {
@@ -431,6 +547,8 @@ static int run_job(qs_hip_job* job, int flags, int niter, int progprec,
   if (!hc) return fail(QS_HIP_ENOMEM, "out of host memory");
   struct HcFree { QsConsts* p; ~HcFree() { delete[] p; } } hc_free{hc};
 
+  const double t_start = wall_ms();
+  double t_upload = 0;
   Comp comp[QS_HIP_MAXC];
   // planes that outlive their component (reference image1 / image2, :2753-2815)
   DevBuf d_yfull, d_llow;          // full-res luma plane; luma at chroma resolution
@@ -465,7 +583,7 @@ static int run_job(qs_hip_job* job, int flags, int niter, int progprec,
     HIP_TRY(C.status.alloc(sizeof(int32_t)));
     if (int r = qs_hip_consts_build(&hc[ci], job->quant[ci], flags)) return r;
     HIP_TRY(hipMemcpyAsync(C.cst.p, &hc[ci], sizeof(QsConsts), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(C.coef.p, job->coef[ci], cbytes, hipMemcpyHostToDevice, s));
+    { const double t0 = wall_ms(); HIP_TRY(upload(C.coef.p, job->coef[ci], cbytes, s, C.stage)); t_upload += wall_ms() - t0; }
     HIP_TRY(hipMemsetAsync(C.status.p, 0, sizeof(int32_t), s));
 
     bool have_plane = false;
@@ -564,7 +682,9 @@ static int run_job(qs_hip_job* job, int flags, int niter, int progprec,
   }
 
   // ---- everything is enqueued; eager mode reads the range-check flags now
+  const double t_enq = wall_ms();
   for (int i = 0; i < nstreams; ++i) HIP_TRY(hipStreamSynchronize(st.s[i]));
+  const double t_done = wall_ms();
   if (eager)
     for (int ci = 0; ci < job->ncomp; ++ci)
       if (comp[ci].processed && !comp[ci].dequant_only) {
@@ -584,6 +704,9 @@ static int run_job(qs_hip_job* job, int flags, int niter, int progprec,
                              hipMemcpyDeviceToHost, st.s[0]));
   }
   HIP_TRY(hipStreamSynchronize(st.s[0]));
+  if (trace_on())
+    fprintf(stderr, "qs_hip trace: %s  enqueue %.2f ms (host->pinned->device issue %.2f)  drain %.2f ms  download %.2f ms\n",
+            eager ? "eager" : "careful", t_enq - t_start, t_upload, t_done - t_enq, wall_ms() - t_done);
 
   if (!stop && have_yfull && up_host[0] && up_host[1]) {  // reference :2836-2849
     job->coef_up[0] = up_host[0]; job->coef_up[1] = up_host[1]; up_free.keep = true;
@@ -603,6 +726,8 @@ extern "C" void qs_hip_release_cache(void) {
   g_cache.clear();
   for (auto* sp : g_stream_pool) delete sp;
   g_stream_pool.clear();
+  for (auto& c : PinnedBuf::pool()) (void)hipHostFree(c.p);
+  PinnedBuf::pool().clear();
 }
 
 extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int progprec,

@@ -9,14 +9,32 @@ sys.path.insert(0, str(ROOT))
 import jpegqs_pkg
 pkg = jpegqs_pkg.load(); hip = pkg.HipQS(); synth = pkg.synth
 
-def run(name, coefs, quants, flags, niter, **kw):
+import ctypes as C
+from jpeg_quantsmooth_amd import hipqs
+
+
+def run(name, coefs, quants, flags, niter, hsamp=None, vsamp=None, colorspace=None, image_size=None):
+    """times the C entry point itself (the Python wrapper's defensive copies are outside the clock)"""
+    n = len(coefs)
     nblk = sum(c.shape[0] * c.shape[1] for c in coefs)
     ts = []
-    for rep in range(4):
-        t0 = time.perf_counter(); hip.do_quantsmooth(coefs, quants, flags, niter, **kw); ts.append(time.perf_counter() - t0)
-    # the python wrapper copies the inputs (np.copy) before the call: measure that and subtract
-    t0 = time.perf_counter(); _ = [c.copy() for c in coefs]; tcopy = time.perf_counter() - t0
-    best = min(ts[1:]) - tcopy
+    for rep in range(5):
+        job = hipqs.Job(); job.ncomp = n
+        job.colorspace = colorspace if colorspace is not None else (3 if n == 3 else 1)
+        work = [np.ascontiguousarray(c).copy() for c in coefs]
+        for ci in range(n):
+            job.hblk[ci], job.wblk[ci] = work[ci].shape[:2]
+            job.hsamp[ci], job.vsamp[ci] = (hsamp or [1] * n)[ci], (vsamp or [1] * n)[ci]
+            job.coef[ci] = work[ci].ctypes.data; job.has_quant[ci] = 1
+            for i in range(64): job.quant[ci][i] = int(quants[ci][i])
+        job.image_width, job.image_height = image_size or (work[0].shape[1] * 8, work[0].shape[0] * 8)
+        t0 = time.perf_counter()
+        rc = hip.lib.qs_hip_do_quantsmooth(C.byref(job), flags, niter, 0, C.cast(None, hipqs.PROGRESS_FN), None)
+        ts.append(time.perf_counter() - t0)
+        assert rc == 0, hip.lib.qs_hip_last_error()
+        for j in range(2):
+            if job.coef_up[j]: hip.lib.qs_hip_free(job.coef_up[j])
+    best = min(ts[1:])
     print(f"{name:46s} blocks={nblk:8d} first={ts[0]*1e3:8.2f} ms  steady={best*1e3:8.2f} ms  {nblk/best/1e6:8.2f} Mblocks/s (PCIe-inclusive)", flush=True)
 
 c, q = synth.synth_gray(64, 64, 50); run("C0 64x64 gray q3 n3", [c], [q], 0, 3)
