@@ -248,3 +248,30 @@ def test_gpu_job_layer_is_thread_safe(gpu, oracle, synth):
         t.join()
     assert not errors, errors
     gpu.lib.qs_hip_release_cache()
+
+
+def test_gpu_fuzz_random_jobs(gpu, oracle, synth):
+    """seeded random jobs: size, chroma layout, JPEG quality (incl. the extremes:
+    quantisers of 1 and of 255), every flag combination, niter 0..3, sparse and
+    dense coefficient planes -- GPU vs oracle, bit-exact"""
+    rng = np.random.default_rng(20260925)
+    layouts = [(1, 1), (2, 2), (2, 1), (1, 2), (4, 1)]
+    for trial in range(48):
+        w, h = int(rng.integers(8, 180)), int(rng.integers(8, 140))
+        qual = int(rng.choice([1, 5, 20, 50, 80, 95, 100]))
+        flags = int(rng.integers(0, 64))
+        niter = int(rng.integers(0, 4))
+        if trial % 3 == 0:
+            coef, quant = synth.synth_gray(w, h, qual, seed=trial)
+            if trial % 6 == 0:  # sparse plane: mostly zero blocks
+                coef = (coef * (rng.random(coef.shape[:2]) < 0.3)[:, :, None]).astype(np.int16)
+            a = gpu.do_quantsmooth([coef], [quant], flags, niter)
+            b = oracle.do_quantsmooth([coef], [quant], flags, niter)
+            assert_same_result(a, b, f"trial {trial}: gray {w}x{h} q{qual} flags={flags} niter={niter}")
+        else:
+            hs, vs = layouts[int(rng.integers(0, len(layouts)))]
+            j = synth.synth_ycc(w, h, hs, vs, quality=qual, seed=trial)
+            kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(w, h))
+            a = gpu.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+            b = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+            assert_same_result(a, b, f"trial {trial}: ycc {w}x{h} {hs}x{vs} q{qual} flags={flags} niter={niter}")
