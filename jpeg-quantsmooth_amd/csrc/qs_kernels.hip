@@ -307,19 +307,16 @@ __device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
 #ifndef QS_PIN_EDGE
 #define QS_PIN_EDGE 1
 #endif
-// Explicit double-buffered scalar weight prefetch (QS_STEP below).  Measured on
-// MI355X: it makes 2-3 waves/SIMD as fast as 4, but at 4 waves/SIMD (the
-// default) the compiler's own s_load placement is already covered by the other
-// waves and is ~3% faster, so it is off by default and kept for the
-// lower-occupancy, more-registers variants.
-#ifndef QS_SMEM_PIPELINE
-#define QS_SMEM_PIPELINE 0
-#endif
+// Explicit double-buffered scalar weight prefetch (QS_STEP below), used by the
+// low-occupancy kernel variant.  Measured on MI355X: with 4 waves per SIMD in
+// flight the compiler's own s_load placement is covered by the other waves and
+// is a few % faster; with 1-2 waves per SIMD (planes below ~190k blocks, e.g. a
+// 1/8 band of an 8192^2 image) the explicit pipeline is 25-75 % faster.
 typedef float qs_w16 __attribute__((ext_vector_type(16)));
 // explicit scalar loads: the compiler does not know about them, so the wait is
 // tied to the buffer through a "+s" operand (uses cannot move above it)
 #define QS_SLOAD16(BUF, BYTEOFF) \
-  asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(BUF) : "s"(tabp), "s"((uint32_t)(BYTEOFF)) : "memory")
+  asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(BUF) : "s"(tabp), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)(BYTEOFF))) : "memory")
 #define QS_SWAIT(BUF) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(BUF) : : "memory")
 // One pipeline step: wait for the chunk in CUR, then immediately issue the load
 // of the following chunk into NXT.  The num/den operands pin the step between
@@ -329,10 +326,7 @@ typedef float qs_w16 __attribute__((ext_vector_type(16)));
 #define QS_STEP(CUR, NXT, BYTEOFF) \
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %1, %4, %5" \
                : "+s"(CUR), "=&s"(NXT), "+v"(num), "+v"(den) \
-               : "s"(tabp), "s"((uint32_t)(BYTEOFF)) : "memory")
-#ifndef QS_SMOOTH_MIN_WAVES
-#define QS_SMOOTH_MIN_WAVES 4 /* waves per SIMD the register allocator must leave room for */
-#endif
+               : "s"(tabp), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)(BYTEOFF))) : "memory")
 
 __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >> (8 * n)) & 0xffu); }
 
@@ -342,236 +336,6 @@ __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >
 #define QS_WAVES_PER_WG 4
 #endif
 
-template <bool DIAG>
-__global__ void __launch_bounds__(64 * QS_WAVES_PER_WG, QS_SMOOTH_MIN_WAVES)
-qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
-                       const uint8_t* __restrict__ plane, int wblk, int hblk, int pitch,
-                       int rebalance, int final_clamp, int blk_begin, int blk_end) {
-  // blocks [blk_begin, blk_end) of the plane (linear, row-major): the whole
-  // plane, or the interior / the edge block rows of a band when the halo
-  // exchange is overlapped with the interior (bands.py)
-  __shared__ uint32_t lds_all[QS_WAVES_PER_WG][32 * QS_LDS_PITCH];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* lds = lds_all[wave];
-  uint32_t* col = lds + lane;
-  const int nblk = blk_end;
-  const int base = blk_begin + (blockIdx.x * QS_WAVES_PER_WG + wave) * 64;
-  if (base >= nblk) return;  // wave-uniform
-  const int nvec = min(64, nblk - base) * 8;
-
-  // ---- stage the wave's 64 blocks (8 KiB contiguous): 16 B per lane per
-  // load, fully coalesced, transposed through LDS into per-lane columns.
-  uint4* gsrc = reinterpret_cast<uint4*>(coef) + (size_t)base * 8;
-  {
-    const int m0 = (lane & 7) * 4;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int idx = j * 64 + lane;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (idx < nvec) v = gsrc[idx];
-      uint32_t* dst = lds + m0 * QS_LDS_PITCH + (j * 8 + (lane >> 3));
-      dst[0] = v.x; dst[QS_LDS_PITCH] = v.y; dst[2 * QS_LDS_PITCH] = v.z; dst[3 * QS_LDS_PITCH] = v.w;
-    }
-  }
-
-  // ---- neighbour edge pixels from the frozen plane (reference :1396-1401),
-  // kept packed (4 per VGPR): [0..1] row above, [2..3] row below,
-  // [4..5] column to the left, [6..7] column to the right
-  const int blk = min(base + lane, nblk - 1);
-  const int by = blk / wblk, bx = blk - by * wblk;
-  const uint8_t* org = plane + (size_t)(by * 8 + 1) * pitch + QS_APRON_X + bx * 8;
-  uint32_t edge[8];
-  {
-    const uint2 t = *reinterpret_cast<const uint2*>(org - pitch);
-    const uint2 b = *reinterpret_cast<const uint2*>(org + (size_t)8 * pitch);
-    edge[0] = t.x; edge[1] = t.y; edge[2] = b.x; edge[3] = b.y;
-    uint32_t l[8], r[8];
-#pragma unroll
-    for (int y = 0; y < 8; ++y) {
-      l[y] = org[(ptrdiff_t)y * pitch - 1];
-      r[y] = org[(ptrdiff_t)y * pitch + 8];
-    }
-    edge[4] = l[0] | (l[1] << 8) | (l[2] << 16) | (l[3] << 24);
-    edge[5] = l[4] | (l[5] << 8) | (l[6] << 16) | (l[7] << 24);
-    edge[6] = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
-    edge[7] = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
-  }
-  wave_lds_sync();
-#if QS_IDCT_DOT2
-  {  // row-major pairs (c[r][2j], c[r][2j+1]) -> column pairs of QS_IDCT_DOT2, in place, own column only
-    uint32_t rm[32];
-#pragma unroll
-    for (int m = 0; m < 32; ++m) rm[m] = col[m * QS_LDS_PITCH];
-#pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      constexpr int ra[4] = {0, 2, 7, 3}, rb[4] = {4, 6, 5, 1};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const uint32_t a = rm[ra[t] * 4 + (x >> 1)], b = rm[rb[t] * 4 + (x >> 1)];
-        const uint32_t lo = (x & 1) ? (a >> 16) : (a & 0xffffu);
-        const uint32_t hi = (x & 1) ? (b & 0xffff0000u) : (b << 16);
-        col[(4 * x + t) * QS_LDS_PITCH] = lo | hi;
-      }
-    }
-  }
-#endif
-
-  constexpr int TS = DIAG ? 272 : 160;
-  float px[64];   // own pixels * 2^-12
-  float bd[32];   // own edge pixel minus neighbour pixel, * 2^-12 (top, bottom, left, right)
-
-  // 14 zigzag anti-diagonals; the block's own pixels are re-derived from its
-  // current coefficients at the start of each (reference :313-322, 1407-1409;
-  // refreshing unconditionally is identical to refreshing "if stale").
-  int kfirst = 63;
-#if QS_SMEM_PIPELINE
-  const float* tabp = cst->tab;
-  qs_w16 WA, WB;
-  int i_cur = 63;                        // natural index of zigzag position 63
-  QS_SLOAD16(WA, (uint32_t)63 * (TS * 4));   // 63 & 7 != 0: the H section comes first
-#endif
-#pragma unroll 1
-  for (int g = 0; g < 14; ++g) {
-#ifdef QS_ABLATE_IDCT
-    if (g == 0)
-#endif
-    {
-      uint32_t ws[64];
-#if QS_IDCT_DOT2
-#pragma unroll
-      for (int x = 0; x < 8; ++x) {
-        uint32_t o[8];
-        idct_col_dot2(col[(4 * x + 0) * QS_LDS_PITCH], col[(4 * x + 1) * QS_LDS_PITCH],
-                      col[(4 * x + 2) * QS_LDS_PITCH], col[(4 * x + 3) * QS_LDS_PITCH], o);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ws[j * 8 + x] = o[j];
-      }
-#else
-#pragma unroll
-      for (int m = 0; m < 32; ++m) {
-        const uint32_t d = col[m * QS_LDS_PITCH];
-        ws[2 * m] = (uint32_t)(int32_t)(int16_t)(d & 0xffff);
-        ws[2 * m + 1] = (uint32_t)((int32_t)d >> 16);
-      }
-      idct_pass1(ws);
-#endif
-#pragma unroll
-      for (int y = 0; y < 8; ++y) {
-        uint32_t row[8]; int o[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) row[j] = ws[y * 8 + j];
-        idct_pass2_row(row, o);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) px[y * 8 + j] = (float)o[j] * QS_PIX_SCALE;
-      }
-      // the 32 edge differences only change here, not per coefficient
-      // (see QS_PIN_EDGE above for the optional opaque barrier)
-#if QS_PIN_EDGE
-#pragma unroll
-      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(edge[e]));
-#endif
-#pragma unroll
-      for (int x = 0; x < 8; ++x) {
-        bd[x]      = px[x]         - byte_f(edge[0 + (x >> 2)], x & 3) * QS_PIX_SCALE;
-        bd[8 + x]  = px[56 + x]    - byte_f(edge[2 + (x >> 2)], x & 3) * QS_PIX_SCALE;
-        bd[16 + x] = px[x * 8]     - byte_f(edge[4 + (x >> 2)], x & 3) * QS_PIX_SCALE;
-        bd[24 + x] = px[x * 8 + 7] - byte_f(edge[6 + (x >> 2)], x & 3) * QS_PIX_SCALE;
-      }
-    }
-    // anti-diagonal g (walking down from k = 63) holds min(g + 1, 15 - g) coefficients
-    const int len = min(g + 1, 15 - g);
-    const int klast = max(kfirst - len + 1, 1);
-#pragma unroll 1
-    for (int k = kfirst; k >= klast; --k) {
-#if QS_PIN_DIFFS
-      // Keep the interior pixel differences inside the coefficient loop:
-      // otherwise the compiler hoists all 112/210 of them out of the k-loop
-      // (they only change per anti-diagonal) and pays for it in VGPRs /
-      // scratch spills.
-#pragma unroll
-      for (int p = 0; p < 64; ++p) asm volatile("" : "+v"(px[p]));
-#endif
-      // quantiser scalars for the update below: fetched here, not inside the
-      // divergent branch where their latency would be exposed every time
-      int qk = cst->q[k], x1k = cst->x1[k], x2k = cst->x2[k];
-      asm volatile("" : "+s"(qk), "+s"(x1k), "+s"(x2k));
-#if QS_SMEM_PIPELINE
-      // Weights stream through two 16-SGPR buffers (WA/WB): the s_load of the
-      // next 16-float chunk is issued right after the wait for the current
-      // one, so its latency hides behind ~140 VALU instructions instead of
-      // stalling the wave ~20 times per coefficient (the compiler otherwise
-      // places every scalar load a few instructions before its first use).
-      // Section lengths before any chunk are even (H 4, B 2, V 4 chunks), so a
-      // section always starts in WA; the first chunk of the next coefficient
-      // is prefetched from the last chunk of this one, across the IDCT refresh
-      // and the coefficient update.
-      const int i = i_cur;
-      const int i_nxt = cst->nat[k > 1 ? k - 1 : 1];
-      const float Rs = cst->range[k];   // 2q * 2^-12
-      const uint32_t kb = (uint32_t)k * (TS * 4);
-      const uint32_t next_first = (uint32_t)(k > 1 ? k - 1 : 1) * (TS * 4) + ((i_nxt & 7) ? 0u : 256u);
-      const uint32_t after_V = DIAG ? kb + 640u : next_first;
-      const uint32_t after_B = (i > 7) ? kb + 384u : after_V;
-      float num = 0.0f, den = 0.0f;
-
-#define QS_ROWS_H(W, Y0) { \
-        _Pragma("unroll") for (int yy = 0; yy < 2; ++yy) \
-        _Pragma("unroll") for (int x = 0; x < 7; ++x) \
-          QS_TERM(px[((Y0) + yy) * 8 + x], px[((Y0) + yy) * 8 + x + 1], W[yy * 8 + x]) }
-#define QS_ROWS_V(W, Y0, NY) { \
-        _Pragma("unroll") for (int yy = 0; yy < (NY); ++yy) \
-        _Pragma("unroll") for (int x = 0; x < 8; ++x) \
-          QS_TERM(px[((Y0) + yy) * 8 + x], px[((Y0) + yy) * 8 + x + 8], W[yy * 8 + x]) }
-#define QS_ROW_D(W, Y) { \
-        _Pragma("unroll") for (int x = 0; x < 7; ++x) { \
-          QS_TERM(px[(Y) * 8 + x], px[(Y) * 8 + x + 9], W[x]) \
-          QS_TERM(px[(Y) * 8 + x + 1], px[(Y) * 8 + x + 8], W[8 + x]) } }
-#define QS_EDGE16(W, J0) { \
-        _Pragma("unroll") for (int j = 0; j < 16; ++j) QS_TERM_D(bd[(J0) + j], W[j]) }
-
-      if (i & 7) {
-        QS_STEP(WA, WB, kb + 64u);  QS_ROWS_H(WA, 0)
-        QS_STEP(WB, WA, kb + 128u); QS_ROWS_H(WB, 2)
-        QS_STEP(WA, WB, kb + 192u); QS_ROWS_H(WA, 4)
-        QS_STEP(WB, WA, kb + 256u); QS_ROWS_H(WB, 6)
-      }
-      QS_STEP(WA, WB, kb + 320u);   QS_EDGE16(WA, 0)
-      QS_STEP(WB, WA, after_B);     QS_EDGE16(WB, 16)
-      if (i > 7) {
-        QS_STEP(WA, WB, kb + 448u); QS_ROWS_V(WA, 0, 2)
-        QS_STEP(WB, WA, kb + 512u); QS_ROWS_V(WB, 2, 2)
-        QS_STEP(WA, WB, kb + 576u); QS_ROWS_V(WA, 4, 2)
-        QS_STEP(WB, WA, after_V);   QS_ROWS_V(WB, 6, 1)
-      }
-      if (DIAG) {
-        QS_STEP(WA, WB, kb + 704u);  QS_ROW_D(WA, 0)
-        QS_STEP(WB, WA, kb + 768u);  QS_ROW_D(WB, 1)
-        QS_STEP(WA, WB, kb + 832u);  QS_ROW_D(WA, 2)
-        QS_STEP(WB, WA, kb + 896u);  QS_ROW_D(WB, 3)
-        QS_STEP(WA, WB, kb + 960u);  QS_ROW_D(WA, 4)
-        QS_STEP(WB, WA, kb + 1024u); QS_ROW_D(WB, 5)
-        QS_STEP(WA, WB, next_first); QS_ROW_D(WA, 6)
-        WA = WB;  // 7 chunks: restore the "first chunk is in WA" invariant
-      }
-      i_cur = i_nxt;
-#else
-      const int i = cst->nat[k];
-      const float Rs = cst->range[k];   // 2q * 2^-12
-      const float* __restrict__ w = cst->tab + k * TS;
-      float num = 0.0f, den = 0.0f;
-
-      // Structural zeros: for horizontal frequency u = i & 7 the weight
-      // T[p] - T[p+1] vanishes exactly whenever (x + 1) * u is a multiple of 8
-      // (the two cosines coincide): x = 1,3,5 for u = 4 and x = 3 for u = 2,4,6;
-      // same for the vertical differences with v = i >> 3 (whole rows y).  A zero
-      // weight makes y = 0, so the term adds +0 to both sums -- skipping it is
-      // exact (the host verifies the table entries are 0.0f,
-      // qs_hip_consts_build).  That is 7.7 % of all terms at q3.
-      // Mechanism: the 48 "optional" terms are emitted as inline-asm blocks that
-      // carry their own wave-uniform scalar test and branch, so the compiler
-      // sees straight-line code (branching in C++ made hipcc spill 240-430
-      // B/lane and run 1.7x slower).  skip4 = 1 when the frequency is 4, even = 1
-      // when it is 2, 4 or 6.
 #if QS_SKIP_ZERO_WEIGHTS
 #define QS_TERM_OPT(COND, A, B, W) { float d_, t_; \
         asm volatile( \
@@ -592,142 +356,28 @@ qs_smooth_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ c
 #else
 #define QS_TERM_OPT(COND, A, B, W) QS_TERM(A, B, W)
 #endif
-      if (i & 7) {
-        const int u = __builtin_amdgcn_readfirstlane(i & 7);   // wave-uniform by construction
-        // plain bit arithmetic (a compare would be materialised in a VGPR, which the "s" operands reject)
-        const int skip4 = __builtin_amdgcn_readfirstlane((u >> 2) & (~u >> 1) & ~u & 1);
-        const int even = __builtin_amdgcn_readfirstlane(~u & 1);
-        (void)skip4; (void)even;
-#pragma unroll
-        for (int y = 0; y < 8; ++y)
-#pragma unroll
-          for (int x = 0; x < 7; ++x) {
-            if (x == 3) QS_TERM_OPT(even, px[y * 8 + x], px[y * 8 + x + 1], w[y * 8 + x])
-            else if (x & 1) QS_TERM_OPT(skip4, px[y * 8 + x], px[y * 8 + x + 1], w[y * 8 + x])
-            else QS_TERM(px[y * 8 + x], px[y * 8 + x + 1], w[y * 8 + x])
-          }
-      }
-#pragma unroll
-      for (int j = 0; j < 32; ++j) QS_TERM_D(bd[j], w[64 + j])
-      if (i > 7) {
-        const int v = __builtin_amdgcn_readfirstlane(i >> 3);
-        const int skip4 = __builtin_amdgcn_readfirstlane((v >> 2) & (~v >> 1) & ~v & 1);
-        const int even = __builtin_amdgcn_readfirstlane(~v & 1);
-        (void)skip4; (void)even;
-#pragma unroll
-        for (int y = 0; y < 7; ++y)
-#pragma unroll
-          for (int x = 0; x < 8; ++x) {
-            if (y == 3) QS_TERM_OPT(even, px[y * 8 + x], px[y * 8 + x + 8], w[96 + y * 8 + x])
-            else if (y & 1) QS_TERM_OPT(skip4, px[y * 8 + x], px[y * 8 + x + 8], w[96 + y * 8 + x])
-            else QS_TERM(px[y * 8 + x], px[y * 8 + x + 8], w[96 + y * 8 + x])
-          }
-      }
-#undef QS_TERM_OPT
-      if (DIAG) {
-#pragma unroll
-        for (int y = 0; y < 7; ++y)
-#pragma unroll
-          for (int x = 0; x < 7; ++x) {
-            QS_TERM(px[y * 8 + x], px[y * 8 + x + 9], w[160 + y * 16 + x])
-            QS_TERM(px[y * 8 + x + 1], px[y * 8 + x + 8], w[168 + y * 16 + x])
-          }
-      }
 
+// Two instantiations of the kernel body (qs_smooth_kernel.inc): variant 0 leaves
+// the scalar weight loads to the compiler (4 waves/SIMD), variant 1
+// (`_lowocc`, the default -- see qs_launch_smooth_plane) streams them through an
+// explicit double buffer and does not depend on other waves to hide latency.
+#define QS_SMOOTH_KERNEL_NAME qs_smooth_plane_kernel
+#define QS_SMEM_PIPELINE 0
+#ifndef QS_SMOOTH_MIN_WAVES
+#define QS_SMOOTH_MIN_WAVES 4
 #endif
-      // num'/den' = (num/den) * 2^-12: undo the scale (exact), then round
-#ifdef QS_ABLATE_UPDATE
-      if (num == 123.456f) lds_set_coef(col, i, (int)den);
-      continue;
-#endif
-      const int r = f2i_x86(round_half_away((num / den) * 4096.0f));
-      if (r != 0) {
-        const int c0 = lds_coef(col, i);
-        int orig, lo, hi;
-        interval(c0, qk, x1k, x2k, orig, lo, hi);
-        int v = (int)((uint32_t)c0 - (uint32_t)r);  // wraps like the x86 build
-        v = min(max(v, lo), hi);
-        lds_set_coef(col, i, v);
-      }
-    }
-    kfirst = klast - 1;
-  }
+#include "qs_smooth_kernel.inc"
+#undef QS_SMOOTH_KERNEL_NAME
+#undef QS_SMEM_PIPELINE
+#undef QS_SMOOTH_MIN_WAVES
 
-#if QS_SMEM_PIPELINE
-  QS_SWAIT(WA);  // drain the last (unused) prefetch before the wave moves on
-#endif
-
-  // ---- rebalance (reference :1823-1848): scale AC energy back towards the
-  // quantised original, inside each coefficient's interval.
-  if (rebalance) {
-    long long m0 = 0, m1 = 0;
-#pragma unroll 9
-    for (int n = 1; n < 64; ++n) {
-      const int c = lds_coef(col, n);
-      int orig, lo, hi;
-      interval(c, cst->qn[n], cst->x1n[n], cst->x2n[n], orig, lo, hi);
-      m0 += (long long)(c * orig);
-      m1 += (long long)(orig * orig);
-    }
-    if (m1 > m0) {
-      const int mul = (int)(((m1 << 13) + (m0 >> 1)) / m0);
-#pragma unroll 9
-      for (int n = 1; n < 64; ++n) {
-        const int c = lds_coef(col, n);
-        int orig, lo, hi;
-        interval(c, cst->qn[n], cst->x1n[n], cst->x2n[n], orig, lo, hi);
-        int v = (c * mul + 0x1000) >> 13;
-        v = min(max(v, lo), hi);
-        lds_set_coef(col, n, v);
-      }
-    }
-  }
-#if QS_IDCT_DOT2
-  {  // back to row-major pairs for the coalesced write-back
-    uint32_t cp[32];
-#pragma unroll
-    for (int m = 0; m < 32; ++m) cp[m] = col[m * QS_LDS_PITCH];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int t = pair_slot(r), h = pair_half(r);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t a = cp[4 * (2 * j) + t], b = cp[4 * (2 * j + 1) + t];
-        const uint32_t lo = h ? (a >> 16) : (a & 0xffffu);
-        const uint32_t hi = h ? (b & 0xffff0000u) : (b << 16);
-        col[(r * 4 + j) * QS_LDS_PITCH] = lo | hi;
-      }
-    }
-  }
-#endif
-  wave_lds_sync();
-
-  // ---- write back, coalesced; optional final +-1023 clamp (reference :2680-2686)
-  {
-    // recompute the per-lane store addresses from an opaque copy of the lane
-    // id, so that the 8 load addresses of the prologue do not stay live (and
-    // get spilled) across the whole kernel
-    int lane2 = lane;
-    asm volatile("" : "+v"(lane2));
-    const int lane = lane2;
-    const int m0 = (lane & 7) * 4;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int idx = j * 64 + lane;
-      const uint32_t* s = lds + m0 * QS_LDS_PITCH + (j * 8 + (lane >> 3));
-      uint32_t d[4] = {s[0], s[QS_LDS_PITCH], s[2 * QS_LDS_PITCH], s[3 * QS_LDS_PITCH]};
-      if (final_clamp) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          int lo = (int16_t)(d[c] & 0xffff), hi = (int32_t)d[c] >> 16;
-          lo = min(max(lo, -1023), 1023); hi = min(max(hi, -1023), 1023);
-          d[c] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
-        }
-      }
-      if (idx < nvec) gsrc[idx] = make_uint4(d[0], d[1], d[2], d[3]);
-    }
-  }
-}
+#define QS_SMOOTH_KERNEL_NAME qs_smooth_plane_kernel_lowocc
+#define QS_SMEM_PIPELINE 1
+#define QS_SMOOTH_MIN_WAVES 3
+#include "qs_smooth_kernel.inc"
+#undef QS_SMOOTH_KERNEL_NAME
+#undef QS_SMEM_PIPELINE
+#undef QS_SMOOTH_MIN_WAVES
 
 // --------------------------------------------------------------------------
 // Kernel C: stand-alone final clamp (used when the last smoothing launch did
@@ -788,12 +438,21 @@ void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* p
   if (n <= 0) return;
   const int per_wg = 64 * QS_WAVES_PER_WG;
   const dim3 grid((n + per_wg - 1) / per_wg), block(per_wg);
-  if (diag)
-    hipLaunchKernelGGL(qs_smooth_plane_kernel<true>, grid, block, 0, s,
-                       cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), rebalance, final_clamp, blk_begin, blk_end);
-  else
-    hipLaunchKernelGGL(qs_smooth_plane_kernel<false>, grid, block, 0, s,
-                       cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), rebalance, final_clamp, blk_begin, blk_end);
+  // Variant 1 (explicit scalar-weight pipeline, 168 VGPRs, no scratch) is the
+  // default at every size: measured A/B on MI355X it is 40-60 % faster than the
+  // compiler-scheduled variant 0 on planes that leave SIMDs with 1-2 waves
+  // (1448^2 .. 2880^2, i.e. also a 1/8 band of 8192^2) and 0-2 % faster on
+  // 4096^2 .. 8192^2.  QS_FORCE_VARIANT=0 selects the other one for A/B runs.
+#ifdef QS_FORCE_VARIANT
+  const bool lowocc = QS_FORCE_VARIANT != 0;
+#else
+  const bool lowocc = true;
+#endif
+  const int pitch = qs_plane_pitch(wblk);
+#define QS_GO(K) hipLaunchKernelGGL(K, grid, block, 0, s, cst, coef, plane, wblk, hblk, pitch, rebalance, final_clamp, blk_begin, blk_end)
+  if (lowocc) { if (diag) QS_GO(qs_smooth_plane_kernel_lowocc<true>); else QS_GO(qs_smooth_plane_kernel_lowocc<false>); }
+  else        { if (diag) QS_GO(qs_smooth_plane_kernel<true>);        else QS_GO(qs_smooth_plane_kernel<false>); }
+#undef QS_GO
 }
 
 void qs_launch_clamp(int16_t* coef, size_t nblk, hipStream_t s) {
