@@ -357,23 +357,25 @@ __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >
 #define QS_TERM_OPT(COND, A, B, W) QS_TERM(A, B, W)
 #endif
 
-// Two instantiations of the kernel body (qs_smooth_kernel.inc): variant 0 leaves
-// the scalar weight loads to the compiler (4 waves/SIMD), variant 1
-// (`_lowocc`, the default -- see qs_launch_smooth_plane) streams them through an
-// explicit double buffer and does not depend on other waves to hide latency.
+// Two instantiations of the kernel body (qs_smooth_kernel.inc):
+//   qs_smooth_plane_kernel      the default: scalar weights streamed through an
+//                               explicit double buffer (QS_STEP), 168 VGPRs, no scratch;
+//                               does not depend on other waves to hide latency
+//   qs_smooth_plane_kernel_alt  weight loads left to the compiler, 128 VGPRs (4 waves
+//                               per SIMD); kept for A/B runs (QS_FORCE_VARIANT=0)
 #define QS_SMOOTH_KERNEL_NAME qs_smooth_plane_kernel
-#define QS_SMEM_PIPELINE 0
+#define QS_SMEM_PIPELINE 1
 #ifndef QS_SMOOTH_MIN_WAVES
-#define QS_SMOOTH_MIN_WAVES 4
+#define QS_SMOOTH_MIN_WAVES 3
 #endif
 #include "qs_smooth_kernel.inc"
 #undef QS_SMOOTH_KERNEL_NAME
 #undef QS_SMEM_PIPELINE
 #undef QS_SMOOTH_MIN_WAVES
 
-#define QS_SMOOTH_KERNEL_NAME qs_smooth_plane_kernel_lowocc
-#define QS_SMEM_PIPELINE 1
-#define QS_SMOOTH_MIN_WAVES 3
+#define QS_SMOOTH_KERNEL_NAME qs_smooth_plane_kernel_alt
+#define QS_SMEM_PIPELINE 0
+#define QS_SMOOTH_MIN_WAVES 4
 #include "qs_smooth_kernel.inc"
 #undef QS_SMOOTH_KERNEL_NAME
 #undef QS_SMEM_PIPELINE
@@ -438,20 +440,19 @@ void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* p
   if (n <= 0) return;
   const int per_wg = 64 * QS_WAVES_PER_WG;
   const dim3 grid((n + per_wg - 1) / per_wg), block(per_wg);
-  // Variant 1 (explicit scalar-weight pipeline, 168 VGPRs, no scratch) is the
-  // default at every size: measured A/B on MI355X it is 40-60 % faster than the
-  // compiler-scheduled variant 0 on planes that leave SIMDs with 1-2 waves
-  // (1448^2 .. 2880^2, i.e. also a 1/8 band of 8192^2) and 0-2 % faster on
-  // 4096^2 .. 8192^2.  QS_FORCE_VARIANT=0 selects the other one for A/B runs.
+  // The pipelined kernel is the default at every size: measured A/B on MI355X it
+  // is 40-60 % faster than the compiler-scheduled one on planes that leave SIMDs
+  // with 1-2 waves (1448^2 .. 2880^2, i.e. also a 1/8 band of 8192^2) and 0-2 %
+  // faster on 4096^2 .. 8192^2.  QS_FORCE_VARIANT=0 selects the other for A/B runs.
 #ifdef QS_FORCE_VARIANT
-  const bool lowocc = QS_FORCE_VARIANT != 0;
+  const bool alt = QS_FORCE_VARIANT == 0;
 #else
-  const bool lowocc = true;
+  const bool alt = false;
 #endif
   const int pitch = qs_plane_pitch(wblk);
 #define QS_GO(K) hipLaunchKernelGGL(K, grid, block, 0, s, cst, coef, plane, wblk, hblk, pitch, rebalance, final_clamp, blk_begin, blk_end)
-  if (lowocc) { if (diag) QS_GO(qs_smooth_plane_kernel_lowocc<true>); else QS_GO(qs_smooth_plane_kernel_lowocc<false>); }
-  else        { if (diag) QS_GO(qs_smooth_plane_kernel<true>);        else QS_GO(qs_smooth_plane_kernel<false>); }
+  if (alt) { if (diag) QS_GO(qs_smooth_plane_kernel_alt<true>); else QS_GO(qs_smooth_plane_kernel_alt<false>); }
+  else     { if (diag) QS_GO(qs_smooth_plane_kernel<true>);     else QS_GO(qs_smooth_plane_kernel<false>); }
 #undef QS_GO
 }
 
