@@ -129,12 +129,14 @@ def run_band(engine: BandEngine, topo: BandTopology, niter: int, exchange) -> No
 
 
 def run_band_overlapped(engine: BandEngine, topo: BandTopology, niter: int, exchange, comm=None) -> None:
-    """Same result, communication hidden: only the first and last block row of a
-    band read the halo rows, so pass B starts on the interior rows right after
-    pass A while the exchange is in flight, and finishes with the edge rows once
-    it has landed.  `comm` = (begin, end) callables that fork the exchange onto a
-    side stream and join it again (HipBandEngine.comm_scope); without it the
-    exchange is simply issued first (CPU engines)."""
+    """Same result, communication hidden.  Only the first and last block row of a
+    band read the halo rows, so after pass A two things proceed side by side:
+      * main stream: pass B on the interior rows;
+      * side stream: the halo exchange, then pass B on the two edge rows (a
+        one-row launch is latency-bound -- a single wave needs ~0.2 ms for its
+        63 coefficient steps -- so it must not be serialised behind the interior).
+    `comm` = HipBandEngine.comm_scope(): (fork, side, join) callables; without it
+    (CPU engines) the same steps simply run in program order."""
     hb = engine.hblk
     lo = 1 if topo.up is not None else 0                    # edge rows that must wait
     hi = hb - 1 if topo.down is not None else hb
@@ -144,17 +146,20 @@ def run_band_overlapped(engine: BandEngine, topo: BandTopology, niter: int, exch
         last = it == niter - 1
         engine.idct(it == 0, topo.rep_top, topo.rep_bot)
         if comm:
-            comm[0]()
-        exchange()
-        if comm:
-            comm[1](False)                                  # stay forked: do not join yet
+            comm[0]()                                       # mark "pass A done" on the main stream
         engine.smooth_rows(lo, hi, last)                    # interior: no halo dependence
+
+        def edges():
+            exchange()
+            if lo > 0:
+                engine.smooth_rows(0, lo, last)
+            if hi < hb:
+                engine.smooth_rows(hi, hb, last)
         if comm:
-            comm[1](True)                                   # join: halo rows are in place
-        if lo > 0:
-            engine.smooth_rows(0, lo, last)
-        if hi < hb:
-            engine.smooth_rows(hi, hb, last)
+            comm[1](edges)                                  # on the side stream, after the mark
+            comm[2]()                                       # main waits for the side stream
+        else:
+            edges()
 
 
 class HipBandEngine(BandEngine):
@@ -202,27 +207,24 @@ class HipBandEngine(BandEngine):
         return bool(int(self.status.item()))
 
     def comm_scope(self):
-        """(begin, end) for run_band_overlapped: run the halo exchange on a side
-        stream that waits for pass A, and make the compute stream wait for it
-        only before the edge rows"""
+        """(fork, side, join) for run_band_overlapped"""
         torch = self.torch
         if not hasattr(self, "_comm_stream"):
             self._comm_stream = torch.cuda.Stream(device=self.plane.device)
-            self._ctx = None
+            self._mark = torch.cuda.Event()
         main = self._stream if self._stream is not None else torch.cuda.current_stream()
 
-        def begin():
-            self._comm_stream.wait_stream(main)            # after pass A
-            self._ctx = torch.cuda.stream(self._comm_stream)
-            self._ctx.__enter__()                          # collectives issued now sync with the side stream
+        def fork():
+            self._mark.record(main)                        # pass A is complete at this point of the main stream
 
-        def end(join):
-            if self._ctx is not None:
-                self._ctx.__exit__(None, None, None)
-                self._ctx = None
-            if join:
-                main.wait_stream(self._comm_stream)
-        return begin, end
+        def side(fn):
+            self._comm_stream.wait_event(self._mark)
+            with torch.cuda.stream(self._comm_stream):     # kernels and collectives issued by fn go to the side stream
+                fn()
+
+        def join():
+            main.wait_stream(self._comm_stream)
+        return fork, side, join
 
 
 # ---------------------------------------------------------------------------
