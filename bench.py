@@ -54,7 +54,10 @@ def parse_args():
     ap.add_argument("--niter", type=int, default=3)
     ap.add_argument("--jpeg-quality", type=int, default=50, help="JPEG quality of the synthetic input")
     ap.add_argument("--weak", action="store_true", help="give every rank a full size x size plane")
-    ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange halos between the passes instead of behind the interior rows")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N > 1: interior rows on the main stream while halo exchange + edge rows run on a side stream "
+                         "(measured slower on MI355X than the default in-order schedule, see DESIGN.md section 8)")
+    ap.add_argument("--no-overlap", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="CPU baseline sample is NxN pixels")
     ap.add_argument("--verify", action="store_true", help="check rows against the oracle after the run (N > 1: rows around every band edge)")
@@ -187,18 +190,19 @@ def main():
     ev_pairs = []
     sharded = topo.up is not None or topo.down is not None
 
-    comm = eng.comm_scope() if sharded else None
+    comm = eng.comm_scope() if (sharded and args.overlap) else None
     exch = bands.exchange_halo_dist if args.backend == "nccl" else bands.exchange_halo_dist_hostcopy
 
     def step(coef, timed):
         eng.rebind(coef)
         if sharded:
-            # interior rows run while the halo rows travel (bands.run_band_overlapped);
-            # per-kernel event timing is an N = 1 matter (roofline is reported there)
-            if args.no_overlap:
-                bands.run_band(eng, topo, args.niter, lambda: exch(eng, topo, dist))
-            else:
+            # default: pass A, halo exchange, pass B in stream order (bands.run_band); --overlap:
+            # bands.run_band_overlapped.  Per-kernel event timing is an N = 1 matter (roofline is
+            # reported there)
+            if args.overlap:
                 bands.run_band_overlapped(eng, topo, args.niter, lambda: exch(eng, topo, dist), comm=comm)
+            else:
+                bands.run_band(eng, topo, args.niter, lambda: exch(eng, topo, dist))
             return
         for it in range(args.niter):
             eng.idct(it == 0, topo.rep_top, topo.rep_bot)
@@ -267,7 +271,8 @@ def main():
             "config": {"workload": f"{size}x{size} luma plane ({hblk_total * wblk} blocks), jpegqs --quality {args.quality} "
                                    f"(flags={flags}) --niter {args.niter}, synthetic JPEG-quality-{args.jpeg_quality} coefficients",
                        "sharding": "none" if world == 1 else f"{world} block-row bands, 1-pixel-row halo over RCCL per iteration, "
-                                                               "exchange overlapped with the interior rows",
+                                                               + ("exchange overlapped with the interior rows" if args.overlap
+                                                                  else "exchange between pass A and pass B in stream order"),
                        "blocks_per_gpu": band_blocks},
             "roofline": {"bound": "hbm", "kernel": "qs_smooth_plane_kernel", "achieved": achieved_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,

@@ -176,7 +176,7 @@ def test_plane_rows_exchange_gloo(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--no-overlap"]])
+@pytest.mark.parametrize("extra", [[], ["--overlap"]])
 def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one
     process per rank, band split, comm side stream, overlapped schedule), but on ONE
