@@ -355,10 +355,11 @@ def run_colour_bands(bands, exchange) -> None:
         if last_refresh:
             break
         for b in bands:
-            b.pass_b(0, it == niter - 1)
-    if niter == 0:
-        for b in bands:
-            b.clamp(0)
+            b.pass_b(0, False)
+    # the +-1023 clamp comes after the refresh pass: the planes the chroma passes read are
+    # the IDCT of the unclamped luma (reference :2668-2689 sits after the loop)
+    for b in bands:
+        b.clamp(0)
     if b0.L is not None:
         for b in bands:
             b.downsample()
@@ -373,8 +374,8 @@ def run_colour_bands(bands, exchange) -> None:
             if it == niter:
                 break
             for b in bands:
-                b.pass_b(ci, it == niter - 1)
-        if niter == 0 and extra:
+                b.pass_b(ci, it == niter - 1 and not extra)
+        if extra:                                              # as for luma: clamp after the refresh
             for b in bands:
                 b.clamp(ci)
         if b0.upsample:

@@ -616,8 +616,11 @@ static int run_job(qs_hip_job* job, int flags, int niter, int progprec,
         if (bad) { stop = 1; break; }
       }
       if (it == iters) break;                            // refresh-only pass, reference :2622
-      // pass B.  The +-1023 clamp rides on the last launch of the last iteration.
-      const int last = (it == iters - 1);
+      // pass B.  The +-1023 clamp rides on the last launch of the last iteration --
+      // unless a refresh-only pass A follows: the reference clamps after its loop
+      // (:2668-2689), so that refresh (the planes JOINT_YUV / UPSAMPLE_UV read) is the
+      // IDCT of the unclamped coefficients.
+      const int last = (it == iters - 1) && !extra;
       if (flags & QS_LOW_QUALITY) {                      // reference :924-938: never reaches the k-loop
         if (joint) {
           if (int r = qs_hip_joint_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), d_llow.as<uint8_t>(),

@@ -69,6 +69,14 @@ def main():
     j = synth.synth_ycc(96, 64, 2, 1, quality=45)
     kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(96, 64))
     save("ycc422_96x64_q6_n1", ref, j["coefs"], j["quants"], 7, 1, **kw)
+    # blocks whose coefficients exceed +-1023 until the final clamp: the refresh-only pass A that
+    # feeds JOINT_YUV / UPSAMPLE_UV runs BEFORE that clamp (reference :2668-2689 sits after the loop)
+    sys.path.insert(0, str(ROOT / "tests"))
+    from helpers import inject_extreme_blocks
+    j = inject_extreme_blocks(synth.synth_ycc(104, 72, 2, 2, quality=60, seed=5))
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(104, 72))
+    save("ycc420_104x72_extreme_q6_n2", ref, j["coefs"], j["quants"], 7, 2, **kw)
+    save("ycc420_104x72_extreme_q5_n1", ref, j["coefs"], j["quants"], 3, 1, **kw)
 
 
 if __name__ == "__main__":

@@ -45,3 +45,19 @@ def assert_same_result(got, want, what=""):
 
 # flag bits the GPU job layer does not implement (none left)
 GPU_FLAG_MASK_UNSUPPORTED = 0
+
+
+def inject_extreme_blocks(j, seed=7):
+    """blocks whose dequantised DC lies beyond +-1023 with strong low AC terms: their IDCT
+    depends on whether the +-1023 clamp has happened yet"""
+    rng = np.random.default_rng(seed)
+    coefs = [c.copy() for c in j["coefs"]]
+    for ci, (c, q) in enumerate(zip(coefs, j["quants"])):
+        hb, wb = c.shape[:2]
+        for _ in range(max(2, hb * wb // 6)):
+            by, bx = rng.integers(0, hb), rng.integers(0, wb)
+            sgn = 1 if rng.integers(0, 2) else -1
+            c[by, bx, 0] = sgn * (int(rng.integers(1200, 2000)) // int(q[0]))
+            for k in (1, 8, 9, 2, 16):
+                c[by, bx, k] = -sgn * (int(rng.integers(300, 1500)) // int(q[k])) * (1 if rng.integers(0, 2) else -1)
+    return dict(j, coefs=coefs)

@@ -116,7 +116,9 @@ def test_colour_bands_on_one_gpu_equal_unsharded(gpu, pkg, oracle, synth, size, 
     from jpeg_quantsmooth_amd import bands as B
     w, h = size
     hs_, vs_ = samp
-    j = synth.synth_ycc(w, h, hs_, vs_, quality=40, seed=12)
+    from helpers import inject_extreme_blocks
+    # extreme blocks: coefficients beyond +-1023 before the final clamp (the refresh passes must see them unclamped)
+    j = inject_extreme_blocks(synth.synth_ycc(w, h, hs_, vs_, quality=40, seed=12))
     kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(w, h))
     dev = torch.device("cuda:0")
     hby, hbc = j["hblk"][0], j["hblk"][1]

@@ -3,7 +3,7 @@ against the oracle / golden vectors for integer JCOEF output."""
 import numpy as np
 import pytest
 
-from helpers import GPU_FLAG_MASK_UNSUPPORTED, assert_same_result, golden_names, load_golden
+from helpers import GPU_FLAG_MASK_UNSUPPORTED, assert_same_result, golden_names, inject_extreme_blocks, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -59,6 +59,22 @@ def test_gpu_vs_oracle_colour_all_flags(gpu, oracle, synth, size, samp):
         for niter in (0, 2):
             a = gpu.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
             b = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+            assert_same_result(a, b, f"{size} {samp} flags={flags} niter={niter}")
+
+
+@pytest.mark.parametrize("size,samp", [((200, 136), (2, 2)), ((136, 88), (1, 1)), ((176, 72), (2, 1))])
+def test_gpu_colour_refresh_pass_sees_unclamped_coefficients(gpu, oracle, synth, size, samp):
+    """the reference clamps to +-1023 after its iteration loop, so the refresh-only pass A that
+    feeds JOINT_YUV / UPSAMPLE_UV is the IDCT of unclamped coefficients (found on a 1080p frame:
+    the job layer used to clamp in the last pass B, i.e. before that refresh)"""
+    w, h = size
+    j = inject_extreme_blocks(synth.synth_ycc(w, h, samp[0], samp[1], quality=60, seed=5))
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(w, h))
+    for flags in (3, 7, 15, 11, 6):
+        for niter in (1, 3):
+            a = gpu.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+            b = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+            assert b["ret"] == 0
             assert_same_result(a, b, f"{size} {samp} flags={flags} niter={niter}")
 
 

@@ -1,33 +1,52 @@
 #!/usr/bin/env python3
 """Throughput of many small jobs submitted concurrently from host threads (the
 job layer is thread-safe: each call leases its own streams and pooled buffers).
-1920x1080 4:2:0 --quality 3 --niter 3, PCIe-inclusive."""
-import sys, time, threading
+PCIe-inclusive, host arrays in and out.  The threads live in a small C program
+(tools/bench_serving.c, built here) that calls qs_hip_do_quantsmooth directly;
+this script makes the job, checks one result against the oracle and prints the
+C program's JSON lines.
+
+    python tools/bench_serving.py [width height [quality [niter]]]     default 1920 1080 3 3, 4:2:0
+"""
+import struct
+import subprocess
+import sys
 from pathlib import Path
+
 import numpy as np
+
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-import jpegqs_pkg
-from oracle.oracle import Oracle
+import jpegqs_pkg  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+
 pkg = jpegqs_pkg.load(); hip = pkg.HipQS(); synth = pkg.synth
-j = synth.synth_ycc(1920, 1080, 2, 2, 50)
-kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(1920, 1080))
-ref = hip.do_quantsmooth(j["coefs"], j["quants"], 0, 3, **kw)
-want = Oracle().do_quantsmooth(j["coefs"], j["quants"], 0, 3, threads=0, **kw)
-assert all(np.array_equal(a, b) for a, b in zip(ref["coefs"], want["coefs"]))
-nblk = sum(c.shape[0] * c.shape[1] for c in j["coefs"])
-for nthreads in (1, 2, 4, 8, 16):
-    per = 24
-    ok = [True] * nthreads
-    def worker(t):
-        for _ in range(per):
-            r = hip.do_quantsmooth(j["coefs"], j["quants"], 0, 3, **kw)
-            if not all(np.array_equal(a, b) for a, b in zip(r["coefs"], ref["coefs"])):
-                ok[t] = False
-    ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
-    t0 = time.perf_counter()
-    for t in ths: t.start()
-    for t in ths: t.join()
-    dt = time.perf_counter() - t0
-    n = nthreads * per
-    print(f"threads={nthreads:2d}: {n / dt:8.1f} images/s  {n * nblk / dt / 1e6:8.2f} Mblocks/s  all bit-exact={all(ok)}", flush=True)
+w = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
+h = int(sys.argv[2]) if len(sys.argv) > 2 else 1080
+quality = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+niter = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+flags = pkg.flags_for_quality(quality)
+j = synth.synth_ycc(w, h, 2, 2, 50)
+kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(w, h))
+got = hip.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+want = Oracle().do_quantsmooth(j["coefs"], j["quants"], flags, niter, threads=0, **kw)
+assert all(np.array_equal(a, b) for a, b in zip(got["coefs"], want["coefs"])), "GPU result differs from the oracle"
+
+out = Path("/tmp/qs_serving"); out.mkdir(exist_ok=True)
+with open(out / "job.bin", "wb") as f:
+    f.write(struct.pack("<4i", len(j["coefs"]), 3, w, h))
+    for c, q, hs, vs in zip(j["coefs"], j["quants"], j["hsamp"], j["vsamp"]):
+        f.write(struct.pack("<4i", c.shape[1], c.shape[0], hs, vs))
+        f.write(np.asarray(q, dtype="<u2").tobytes())
+    for c in j["coefs"]:
+        f.write(np.ascontiguousarray(c, dtype="<i2").tobytes())
+exe = out / "bench_serving"
+libdir = Path(pkg.lib_path()).parent
+subprocess.check_call(["gcc", "-O2", "-o", str(exe), str(ROOT / "tools" / "bench_serving.c"), f"-I{ROOT / 'include'}",
+                       f"-L{libdir}", "-ljpegqs_hip", f"-Wl,-rpath,{libdir}", "-lpthread"])
+print(f"# {w}x{h} 4:2:0 --quality {quality} --niter {niter}, {sum(c.shape[0] * c.shape[1] for c in j['coefs'])} blocks per image", flush=True)
+for nthreads in (1, 2, 4, 8, 16, 32):
+    per = max(8, 256 // nthreads)
+    r = subprocess.run([str(exe), str(out / "job.bin"), str(flags), str(niter), str(nthreads), str(per)],
+                       capture_output=True, text=True)
+    print(r.stdout.strip() or r.stderr.strip(), flush=True)
