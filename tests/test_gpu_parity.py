@@ -287,7 +287,22 @@ def test_gpu_fuzz_random_jobs(gpu, oracle, synth):
         else:
             hs, vs = layouts[int(rng.integers(0, len(layouts)))]
             j = synth.synth_ycc(w, h, hs, vs, quality=qual, seed=trial)
+            if trial % 2 and qual >= 20:  # coefficients beyond +-1023 until the final clamp
+                j = inject_extreme_blocks(j, seed=trial)
             kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(w, h))
             a = gpu.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
             b = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
             assert_same_result(a, b, f"trial {trial}: ycc {w}x{h} {hs}x{vs} q{qual} flags={flags} niter={niter}")
+
+
+@pytest.mark.parametrize("samp", [(2, 2), (1, 1)])
+def test_gpu_colour_1080p_every_quality(gpu, oracle, synth, samp):
+    """a full-HD YCbCr frame through every --quality level (the size at which the clamp-order
+    bug surfaced: enough blocks for rare content to occur), default niter"""
+    w, h = 1920, 1080
+    j = synth.synth_ycc(w, h, samp[0], samp[1], quality=50)
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(w, h))
+    for flags in (9, 11, 15, 0, 1, 3, 7):              # --quality 0..6 (reference quantsmooth.c:380-393)
+        a = gpu.do_quantsmooth(j["coefs"], j["quants"], flags, 3, **kw)
+        b = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, 3, **kw)
+        assert_same_result(a, b, f"1080p {samp} flags={flags}")
