@@ -71,6 +71,15 @@ typedef int (*qs_hip_progress_fn)(void *userdata, int cur, int max);
  * Returns the reference's `stop` (0 done, 1 cancelled/rejected input) or <0. */
 int qs_hip_do_quantsmooth(qs_hip_job *job, int flags, int niter, int progprec,
 		qs_hip_progress_fn progress, void *userdata);
+/* The same for many jobs in one call (one flags/niter setting for all).  Jobs whose
+ * components are independent of each other (no JOINT_YUV / UPSAMPLE_UV coupling, no
+ * LOW_QUALITY: CLI --quality 3 and 4) are processed TOGETHER: one pass-A and one
+ * pass-B launch per iteration over all their planes, so small images fill the 256 CUs
+ * as a group; the others go through qs_hip_do_quantsmooth one by one.  results[i] =
+ * what qs_hip_do_quantsmooth would have returned for jobs[i].  Returns 0, or < 0 when
+ * the batch as a whole could not run (bad arguments, no device).  Not part of the
+ * reference API: an addition for callers that serve many images. */
+int qs_hip_do_quantsmooth_batch(qs_hip_job *const *jobs, int njobs, int flags, int niter, int *results);
 void qs_hip_free(void *p);
 /* the job layer keeps freed device buffers in a process-wide cache (up to 6 GiB);
  * this returns them to the driver */
@@ -111,6 +120,20 @@ int qs_hip_smooth_plane(const void *d_consts, int16_t *d_coef, const uint8_t *d_
  * the halo rows are still in flight and its first/last row afterwards */
 int qs_hip_smooth_rows(const void *d_consts, int16_t *d_coef, const uint8_t *d_plane,
 		int wblk, int hblk, int row0, int row1, int flags, int luma, int final_clamp, void *stream);
+
+/* pass A / pass B over a SET of whole planes in one launch (any mix of sizes and quant
+ * tables: the components of a job, or of many small jobs).  luma: as in
+ * qs_hip_smooth_plane; d_status: the plane's range-check flag (pass A, first iteration). */
+#define QS_HIP_MAX_PLANES 56
+typedef struct {
+	const void *d_consts;
+	int16_t *d_coef;
+	uint8_t *d_plane;
+	int32_t *d_status;
+	int32_t wblk, hblk, luma, reserved;
+} qs_hip_plane_ref;
+int qs_hip_idct_planes(const qs_hip_plane_ref *refs, int n, int first, void *stream);
+int qs_hip_smooth_planes(const qs_hip_plane_ref *refs, int n, int flags, int final_clamp, void *stream);
 
 /* JOINT_YUV chroma predictor + fdct_clamp for one chroma plane (reference :577-579,
  * 893-921, 343-347, 551-561); d_luma_lowres = luma at this plane's resolution and

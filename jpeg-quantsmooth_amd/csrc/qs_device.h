@@ -43,3 +43,24 @@ struct QsConsts {
 static inline int qs_plane_pitch(int wblk) {
   return ((wblk * 8 + QS_APRON_X + 1) + 63) & ~63;
 }
+
+// A set of planes processed by ONE launch (qs_*_set_kernel): the components of a
+// job, or of many small jobs, share the grid so that small images still fill the
+// 256 CUs and a job costs 2 launches per iteration instead of 2 per component.
+// Passed by value in the kernarg segment (read through the scalar cache).
+#define QS_MAX_PLANES 56
+struct QsPlaneRef {
+  const QsConsts* cst;   // this plane's constants (device)
+  int16_t* coef;         // [hblk][wblk][64]
+  uint8_t* plane;        // pixel plane with apron
+  int32_t* status;       // range-check flag (pass A, first iteration)
+  int32_t wblk, hblk, pitch;
+  int32_t rebalance;     // pass B: run the rebalance step on this plane
+};
+struct QsPlaneSet {
+  int32_t n, pad;
+  // wave0[i] = index of the first 64-block group of plane i in the launch;
+  // wave0[n] = total number of groups.  Unused entries repeat wave0[n].
+  int32_t wave0[QS_MAX_PLANES + 2];
+  QsPlaneRef ref[QS_MAX_PLANES];
+};

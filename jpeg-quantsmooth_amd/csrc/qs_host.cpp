@@ -20,8 +20,12 @@
 #include <new>
 #include <mutex>
 #include <vector>
+#include <deque>
 #include <atomic>
 #include <thread>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <algorithm>
 #include <chrono>
 
@@ -257,6 +261,46 @@ extern "C" int qs_hip_smooth_rows(const void* d_consts, int16_t* d_coef, const u
   return smooth_rows(d_consts, d_coef, d_plane, wblk, hblk, row0, row1, flags, luma, final_clamp, stream, "qs_hip_smooth_rows");
 }
 
+static int build_plane_set(const qs_hip_plane_ref* refs, int n, int flags, QsPlaneSet& set, const char* who) {
+  if (!refs || n < 1 || n > QS_MAX_PLANES) return fail(QS_HIP_EINVAL, "%s: 1..%d planes per launch", who, QS_MAX_PLANES);
+  memset(&set, 0, sizeof set);
+  set.n = n;
+  int w = 0;
+  for (int i = 0; i < n; ++i) {
+    const qs_hip_plane_ref& r = refs[i];
+    if (int e = check_plane_args(r.d_coef, r.d_plane, r.wblk, r.hblk, who)) return e;
+    if (!r.d_consts) return fail(QS_HIP_EINVAL, "%s: null consts", who);
+    set.wave0[i] = w;
+    w += (r.wblk * r.hblk + 63) / 64;
+    QsPlaneRef& R = set.ref[i];
+    R.cst = static_cast<const QsConsts*>(r.d_consts);
+    R.coef = r.d_coef; R.plane = r.d_plane; R.status = r.d_status;
+    R.wblk = r.wblk; R.hblk = r.hblk; R.pitch = qs_plane_pitch(r.wblk);
+    R.rebalance = !(flags & QS_NO_REBALANCE) && (r.luma || !(flags & QS_NO_REBALANCE_UV));
+  }
+  for (int i = n; i < QS_MAX_PLANES + 2; ++i) set.wave0[i] = w;
+  return QS_HIP_OK;
+}
+
+extern "C" int qs_hip_idct_planes(const qs_hip_plane_ref* refs, int n, int first, void* stream) {
+  QsPlaneSet set;
+  if (int r = build_plane_set(refs, n, 0, set, "qs_hip_idct_planes")) return r;
+  if (first)
+    for (int i = 0; i < n; ++i)
+      if (!refs[i].d_status) return fail(QS_HIP_EINVAL, "qs_hip_idct_planes: first pass needs d_status");
+  qs_launch_idct_set(set, first, static_cast<hipStream_t>(stream));
+  return launch_status("qs_hip_idct_planes");
+}
+
+extern "C" int qs_hip_smooth_planes(const qs_hip_plane_ref* refs, int n, int flags, int final_clamp, void* stream) {
+  if (flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV | QS_LOW_QUALITY))
+    return fail(QS_HIP_ENOTSUP, "qs_hip_smooth_planes: flags 0x%x need the cross-component stages", flags);
+  QsPlaneSet set;
+  if (int r = build_plane_set(refs, n, flags, set, "qs_hip_smooth_planes")) return r;
+  qs_launch_smooth_set(set, (flags & QS_DIAGONALS) != 0, final_clamp, static_cast<hipStream_t>(stream));
+  return launch_status("qs_hip_smooth_planes");
+}
+
 extern "C" int qs_hip_clamp_plane(int16_t* d_coef, int wblk, int hblk, void* stream) {
   if (int r = check_plane_args(d_coef, d_coef, wblk, hblk, "qs_hip_clamp_plane")) return r;
   qs_launch_clamp(d_coef, (size_t)wblk * hblk, static_cast<hipStream_t>(stream));
@@ -442,36 +486,172 @@ struct PinnedBuf {
   }
 };
 
-static const size_t kStageMin = (size_t)4 << 20, kStageChunk = (size_t)8 << 20;
-static const int kStageThreads = 4;
 
-// copy `bytes` from pageable `src` to device `dst` on `s`; `stage` must outlive the stream work
-static hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t s, PinnedBuf& stage) {
-  if (bytes < kStageMin || !stage.alloc(bytes))
-    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
-  const size_t nchunks = (bytes + kStageChunk - 1) / kStageChunk;
-  std::vector<std::atomic<int>> done(nchunks);
-  for (auto& d : done) d.store(0);
-  std::vector<std::thread> th;
-  for (int t = 0; t < kStageThreads; ++t)
-    th.emplace_back([&, t] {
-      for (size_t c = 0; c < nchunks; ++c) {
-        const size_t c0 = c * kStageChunk, clen = std::min(kStageChunk, bytes - c0);
-        const size_t part = (clen / kStageThreads + 63) & ~(size_t)63;
-        const size_t o = std::min(clen, (size_t)t * part), e = std::min(clen, o + part);
-        if (e > o) memcpy(static_cast<char*>(stage.p) + c0 + o, static_cast<const char*>(src) + c0 + o, e - o);
-        done[c].fetch_add(1, std::memory_order_release);
-      }
-    });
-  hipError_t err = hipSuccess;
-  for (size_t c = 0; c < nchunks; ++c) {
-    while (done[c].load(std::memory_order_acquire) < kStageThreads) std::this_thread::yield();
-    const size_t c0 = c * kStageChunk, clen = std::min(kStageChunk, bytes - c0);
-    if (err == hipSuccess)
-      err = hipMemcpyAsync(static_cast<char*>(dst) + c0, static_cast<char*>(stage.p) + c0, clen, hipMemcpyHostToDevice, s);
+static const size_t kStageMin = (size_t)2 << 20, kStageChunk = (size_t)8 << 20;
+static const int kStageThreads = 4;   // parts per chunk
+static const int kPoolThreads = 8;    // helper threads (several transfers can be in flight)
+
+// Persistent helper threads for the host halves of the transfers (copying between
+// caller memory and pinned staging).  Leaked on purpose: the threads sleep on the
+// condition variable until the process ends.
+class HostPool {
+ public:
+  struct Task { std::function<void(int)> fn; int n = 0; std::atomic<int> next{0}, done{0}; };
+  typedef std::shared_ptr<Task> Handle;
+  static HostPool& get() { static HostPool* p = new HostPool(kPoolThreads); return *p; }
+  // fn(i) for every i in [0, n) on the helper threads, in index order; returns at once
+  Handle submit(int n, std::function<void(int)> fn) {
+    auto t = std::make_shared<Task>();
+    t->fn = std::move(fn); t->n = n;
+    { std::lock_guard<std::mutex> lk(mu_); q_.push_back(t); }
+    cv_.notify_all();
+    return t;
   }
-  for (auto& x : th) x.join();
+  static void wait(const Handle& t) {
+    while (t->done.load(std::memory_order_acquire) < t->n) std::this_thread::yield();
+  }
+
+ private:
+  explicit HostPool(int helpers) {
+    for (int i = 0; i < helpers; ++i) std::thread([this] { loop(); }).detach();
+  }
+  void loop() {
+    for (;;) {
+      Handle t;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !q_.empty(); });
+        t = q_.front();
+        if (t->next.load(std::memory_order_relaxed) >= t->n) { q_.pop_front(); continue; }
+      }
+      for (;;) {
+        const int i = t->next.fetch_add(1, std::memory_order_relaxed);
+        if (i >= t->n) break;
+        t->fn(i);
+        t->done.fetch_add(1, std::memory_order_release);
+      }
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<Handle> q_;
+};
+
+// One transfer = several pageable pieces that sit back to back (at the given
+// offsets) in one device arena.  `stage` must outlive the stream work.
+struct Piece { void* host; size_t off, len; };
+
+// bytes [lo, hi) of the arena image <-> the pieces that overlap them
+static void copy_range(char* stage, const std::vector<Piece>& pieces, size_t lo, size_t hi, bool to_stage) {
+  for (const Piece& pc : pieces) {
+    const size_t a = std::max(lo, pc.off), e = std::min(hi, pc.off + pc.len);
+    if (e <= a) continue;
+    if (to_stage) memcpy(stage + a, static_cast<const char*>(pc.host) + (a - pc.off), e - a);
+    else memcpy(static_cast<char*>(pc.host) + (a - pc.off), stage + a, e - a);
+  }
+}
+// item i of a transfer = part (i % kStageThreads) of chunk (i / kStageThreads)
+static void copy_item(char* stage, const std::vector<Piece>& pieces, size_t bytes, int i, bool to_stage) {
+  const size_t c0 = (size_t)(i / kStageThreads) * kStageChunk, clen = std::min(kStageChunk, bytes - c0);
+  const size_t part = (clen / kStageThreads + 63) & ~(size_t)63;
+  const size_t o = std::min(clen, (size_t)(i % kStageThreads) * part), e = std::min(clen, o + part);
+  if (e > o) copy_range(stage, pieces, c0 + o, c0 + e, to_stage);
+}
+
+// host -> device: the helpers gather 8 MiB chunks into pinned memory; this thread
+// queues a chunk's DMA as soon as its parts are in, so DMA and gathering overlap
+static hipError_t upload_pieces(void* dst, const std::vector<Piece>& pieces, size_t bytes, hipStream_t s, PinnedBuf& stage) {
+  if (bytes < kStageMin || !stage.alloc(bytes)) {
+    for (const Piece& pc : pieces) {
+      hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + pc.off, pc.host, pc.len, hipMemcpyHostToDevice, s);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  const int nchunks = (int)((bytes + kStageChunk - 1) / kStageChunk);
+  auto done = std::make_shared<std::vector<std::atomic<int>>>(nchunks);
+  for (auto& d : *done) d.store(0);
+  char* stg = static_cast<char*>(stage.p);
+  const std::vector<Piece>* pcs = &pieces;
+  HostPool::Handle h = HostPool::get().submit(nchunks * kStageThreads, [=](int i) {
+    copy_item(stg, *pcs, bytes, i, true);
+    (*done)[i / kStageThreads].fetch_add(1, std::memory_order_release);
+  });
+  hipError_t err = hipSuccess;
+  for (int c = 0; c < nchunks; ++c) {
+    while ((*done)[c].load(std::memory_order_acquire) < kStageThreads) std::this_thread::yield();
+    const size_t c0 = (size_t)c * kStageChunk, clen = std::min(kStageChunk, bytes - c0);
+    if (err == hipSuccess)
+      err = hipMemcpyAsync(static_cast<char*>(dst) + c0, stg + c0, clen, hipMemcpyHostToDevice, s);
+  }
+  HostPool::wait(h);
   return err;
+}
+
+// device -> host in two steps.  issue(): the copy into pinned memory is queued on the
+// stream right behind the kernels that produce the data (8 MiB chunks, one event
+// each), no host wait.  finish(): once the caller knows which pieces it wants, the
+// helpers scatter each chunk to the caller's arrays as its event fires.  (Pageable
+// D2H of a few MiB per call runs at 12-17 GB/s here, this path at the DMA rate; and
+// results reach caller memory only after the range-check flags have been seen.)
+struct Download {
+  PinnedBuf stage;
+  std::vector<hipEvent_t> ev;
+  size_t bytes = 0;
+  bool staged = false;
+  Download() = default;
+  Download(const Download&) = delete;
+  Download& operator=(const Download&) = delete;
+  ~Download() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+
+  hipError_t issue(const void* src, size_t nbytes, hipStream_t s) {
+    bytes = nbytes;
+    staged = nbytes >= kStageMin && stage.alloc(nbytes);
+    if (!staged) return hipSuccess;
+    for (size_t c0 = 0; c0 < bytes; c0 += kStageChunk) {
+      const size_t clen = std::min(kStageChunk, bytes - c0);
+      hipError_t e = hipMemcpyAsync(static_cast<char*>(stage.p) + c0, static_cast<const char*>(src) + c0, clen,
+                                    hipMemcpyDeviceToHost, s);
+      hipEvent_t evt = nullptr;
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&evt, hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+      ev.push_back(evt);
+      if ((e = hipEventRecord(evt, s)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  // everything queued before issue() on the stream has completed when this returns
+  hipError_t wait_first(hipStream_t s) const { return staged ? hipEventSynchronize(ev[0]) : hipStreamSynchronize(s); }
+
+  hipError_t finish(const void* src, const std::vector<Piece>& pieces, hipStream_t s) {
+    if (!staged) {
+      for (const Piece& pc : pieces) {
+        hipError_t e = hipMemcpyAsync(pc.host, static_cast<const char*>(src) + pc.off, pc.len, hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) return e;
+      }
+      return hipStreamSynchronize(s);
+    }
+    // a chunk is handed to the helpers only once it has arrived: a helper never waits
+    // for the GPU, so transfers of other host threads are not held up behind this one
+    const int nchunks = (int)ev.size();
+    char* stg = static_cast<char*>(stage.p);
+    const std::vector<Piece>* pcs = &pieces;
+    const size_t nbytes = bytes;
+    std::vector<HostPool::Handle> hs;
+    hipError_t e = hipSuccess;
+    for (int c = 0; c < nchunks && e == hipSuccess; ++c) {
+      e = hipEventSynchronize(ev[c]);
+      if (e == hipSuccess && !pieces.empty())
+        hs.push_back(HostPool::get().submit(kStageThreads, [=](int t) { copy_item(stg, *pcs, nbytes, c * kStageThreads + t, false); }));
+    }
+    for (auto& h : hs) HostPool::wait(h);
+    return e;
+  }
+};
+
+// copy `bytes` from pageable `src` to device `dst` on `s`
+static hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t s, PinnedBuf& stage) {
+  return upload_pieces(dst, std::vector<Piece>{{const_cast<void*>(src), 0, bytes}}, bytes, s, stage);
 }
 
 struct Streams {
@@ -721,6 +901,175 @@ static int run_job(qs_hip_job* job, int flags, int niter, int progprec,
   return stop;
 }
 
+
+// ---------------------------------------------------------------------------
+// fused execution: jobs whose components are independent of each other (no
+// JOINT_YUV / UPSAMPLE_UV coupling, no LOW_QUALITY, ordinary quant tables) run
+// as plane sets -- ONE pass-A and ONE pass-B launch per iteration for all
+// components of all jobs of a group (qs_*_set_kernel), so that small images
+// fill the chip together and a job does not occupy three hardware queues.
+// Everything else about the job semantics is as in run_job (eager mode): the
+// range-check flags are read once at the end, a job with a set flag is re-run in
+// the careful order from its untouched host input.
+
+static int comp_rebalance(const qs_hip_job* job, int ci, int flags) {
+  const int luma = !ci || job->colorspace != 3;                                     // reference :2639
+  return !(flags & QS_NO_REBALANCE) && (luma || !(flags & QS_NO_REBALANCE_UV));       // :1567-1568
+}
+
+static bool job_needs_lowres(const qs_hip_job* job, int flags) {                     // reference :2447-2453
+  return (flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV)) && job->colorspace == 3 && job->ncomp >= 3 &&
+         job->hsamp[1] == 1 && job->vsamp[1] == 1 && job->hsamp[2] == 1 && job->vsamp[2] == 1;
+}
+
+static bool job_fusable(const qs_hip_job* job, int flags) {
+  static const bool off = getenv("QS_HIP_NO_FUSE") != nullptr;
+  if (off || (flags & QS_LOW_QUALITY) || job_needs_lowres(job, flags)) return false;
+  for (int ci = 0; ci < job->ncomp; ++ci) {
+    if (!job->has_quant[ci]) return false;
+    int acc = 0;
+    for (int i = 0; i < 64; ++i) acc |= job->quant[ci][i];
+    if (acc <= 1 || acc >= 0x800) return false;          // iterations skipped / stop: the general path knows how
+  }
+  return true;
+}
+
+struct FPlane { int job, ci, wb, hb, cst; size_t coef_off, px_off, cbytes; };
+struct FGroup {
+  std::vector<FPlane> planes;
+  std::vector<int> jobs;                  // indices into the caller's job list
+  DevBuf coef, px, cst, status;
+  PinnedBuf stage;
+  std::vector<QsConsts> hc;               // host copies stay alive until the stream is drained
+  PinnedBuf hstatus;                      // range-check flags
+  Download down;                          // results on their way back
+  hipStream_t s = nullptr;
+  size_t blocks = 0, coef_bytes = 0;
+};
+struct DrainGuard {                       // error paths: nothing may be freed while the streams still run
+  Streams* st;
+  ~DrainGuard() { for (auto& x : st->s) (void)hipStreamSynchronize(x); }
+};
+
+// a group of >= 3 waves per SIMD runs at the streaming rate; smaller groups let the upload of one
+// overlap the kernels of the previous and the download of the one before (three streams)
+static const size_t kGroupBlocks = (size_t)200 << 10;
+
+static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int flags, int niter, int* results) {
+  StreamLease lease;
+  if (!lease.p) return fail(QS_HIP_ENODEV, "could not create HIP streams: %s", hipGetErrorString(hipGetLastError()));
+  std::deque<FGroup> groups;
+  DrainGuard drain{lease.p};
+  const double t_start = wall_ms();
+
+  // ---- partition into groups (a job never straddles two)
+  for (int ji : which) {
+    const qs_hip_job* job = jobs[ji];
+    size_t jblocks = 0;
+    for (int ci = 0; ci < job->ncomp; ++ci) jblocks += (size_t)job->wblk[ci] * job->hblk[ci];
+    if (groups.empty() || (int)groups.back().planes.size() + job->ncomp > QS_MAX_PLANES ||
+        (groups.back().blocks && groups.back().blocks + jblocks > kGroupBlocks))
+      groups.emplace_back();
+    FGroup& G = groups.back();
+    G.jobs.push_back(ji);
+    G.blocks += jblocks;
+    for (int ci = 0; ci < job->ncomp; ++ci)
+      G.planes.push_back({ji, ci, job->wblk[ci], job->hblk[ci], -1, 0, 0, (size_t)job->wblk[ci] * job->hblk[ci] * 128});
+  }
+
+  // ---- enqueue every group: upload, niter x (pass A, pass B), status readback
+  const int diag = (flags & QS_DIAGONALS) != 0;
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    FGroup& G = groups[gi];
+    G.s = lease.p->s[gi % 3];
+    const int np = (int)G.planes.size();
+    size_t coef_bytes = 0, px_bytes = 0;
+    std::vector<const uint16_t*> qtabs;
+    for (FPlane& P : G.planes) {
+      P.coef_off = coef_bytes; coef_bytes += P.cbytes;
+      P.px_off = px_bytes; px_bytes += (qs_hip_plane_bytes(P.wb, P.hb) + 255) & ~(size_t)255;
+      const uint16_t* q = jobs[P.job]->quant[P.ci];
+      for (size_t k = 0; k < qtabs.size() && P.cst < 0; ++k)
+        if (!memcmp(qtabs[k], q, 64 * sizeof(uint16_t))) P.cst = (int)k;
+      if (P.cst < 0) { P.cst = (int)qtabs.size(); qtabs.push_back(q); }
+    }
+    HIP_TRY(G.coef.alloc(coef_bytes));
+    HIP_TRY(G.px.alloc(px_bytes));
+    HIP_TRY(G.cst.alloc(qtabs.size() * sizeof(QsConsts)));
+    HIP_TRY(G.status.alloc((size_t)np * sizeof(int32_t)));
+    G.hc.resize(qtabs.size());
+    for (size_t k = 0; k < qtabs.size(); ++k)
+      if (int r = qs_hip_consts_build(&G.hc[k], qtabs[k], flags)) return r;
+    HIP_TRY(hipMemcpyAsync(G.cst.p, G.hc.data(), qtabs.size() * sizeof(QsConsts), hipMemcpyHostToDevice, G.s));
+    std::vector<Piece> pieces;
+    for (const FPlane& P : G.planes) pieces.push_back({jobs[P.job]->coef[P.ci], P.coef_off, P.cbytes});
+    G.coef_bytes = coef_bytes;
+    HIP_TRY(upload_pieces(G.coef.p, pieces, coef_bytes, G.s, G.stage));
+    HIP_TRY(hipMemsetAsync(G.status.p, 0, (size_t)np * sizeof(int32_t), G.s));
+
+    QsPlaneSet set;
+    memset(&set, 0, sizeof set);
+    set.n = np;
+    int w = 0;
+    for (int i = 0; i < np; ++i) {
+      const FPlane& P = G.planes[i];
+      set.wave0[i] = w;
+      w += (P.wb * P.hb + 63) / 64;
+      QsPlaneRef& R = set.ref[i];
+      R.cst = G.cst.as<QsConsts>() + P.cst;
+      R.coef = reinterpret_cast<int16_t*>(G.coef.as<char>() + P.coef_off);
+      R.plane = G.px.as<uint8_t>() + P.px_off;
+      R.status = G.status.as<int32_t>() + i;
+      R.wblk = P.wb; R.hblk = P.hb; R.pitch = qs_plane_pitch(P.wb);
+      R.rebalance = comp_rebalance(jobs[P.job], P.ci, flags);
+    }
+    for (int i = np; i < QS_MAX_PLANES + 2; ++i) set.wave0[i] = w;
+    for (int it = 0; it < niter; ++it) {
+      qs_launch_idct_set(set, it == 0, G.s);
+      qs_launch_smooth_set(set, diag, it == niter - 1, G.s);
+    }
+    HIP_TRY(hipGetLastError());
+    // pinned: a pageable destination would make this call wait for the whole stream
+    if (!G.hstatus.alloc((size_t)np * sizeof(int32_t))) return fail(QS_HIP_ENOMEM, "out of pinned host memory");
+    HIP_TRY(hipMemcpyAsync(G.hstatus.p, G.status.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, G.s));
+    HIP_TRY(G.down.issue(G.coef.p, coef_bytes, G.s));       // to pinned memory, right behind the kernels
+  }
+  const double t_enq = wall_ms();
+
+  // ---- drain group by group; results go back only for jobs whose range check passed
+  std::vector<int> rerun;
+  for (FGroup& G : groups) {
+    HIP_TRY(G.down.wait_first(G.s));
+    const int32_t* hst = static_cast<const int32_t*>(G.hstatus.p);
+    std::vector<Piece> back;
+    for (int ji : G.jobs) {
+      bool bad = false;
+      for (size_t i = 0; i < G.planes.size(); ++i) if (G.planes[i].job == ji && hst[i]) bad = true;
+      if (bad) { rerun.push_back(ji); continue; }           // host input is still untouched
+      for (const FPlane& P : G.planes)
+        if (P.job == ji) back.push_back({jobs[ji]->coef[P.ci], P.coef_off, P.cbytes});
+      results[ji] = 0;
+    }
+    HIP_TRY(G.down.finish(G.coef.p, back, G.s));
+  }
+  if (trace_on())
+    fprintf(stderr, "qs_hip trace: fused  %zu job(s) in %zu group(s)  enqueue %.2f ms  drain+download %.2f ms  (%zu re-run)\n",
+            which.size(), groups.size(), t_enq - t_start, wall_ms() - t_enq, rerun.size());
+  for (int ji : which) {
+    bool again = false;
+    for (int r : rerun) again |= (r == ji);
+    if (again) continue;
+    for (int ci = 0; ci < jobs[ji]->ncomp; ++ci)           // reference :2851-2859
+      for (int i = 0; i < 64; ++i) jobs[ji]->quant[ci][i] = 1;
+  }
+  const double t_clear = wall_ms();
+  groups.clear();                                            // give the arenas back before the re-runs allocate
+  if (trace_on()) fprintf(stderr, "qs_hip trace: fused  release %.2f ms\n", wall_ms() - t_clear);
+  for (int ji : rerun)
+    results[ji] = run_job(jobs[ji], flags, niter, 0, nullptr, nullptr, /*eager=*/false);
+  return QS_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" void qs_hip_release_cache(void) {
@@ -733,30 +1082,63 @@ extern "C" void qs_hip_release_cache(void) {
   PinnedBuf::pool().clear();
 }
 
-extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int progprec,
-                                     qs_hip_progress_fn progress, void* userdata) {
+// validation and the reference's early-outs; returns 1 when there is work to do,
+// 0 when the job is already finished (result 0), < 0 on a bad job
+static int prepare_job(qs_hip_job* job, int flags, int* niter) {
   if (!job || job->ncomp < 1 || job->ncomp > QS_HIP_MAXC)
     return fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: bad job");
   for (int ci = 0; ci < job->ncomp; ++ci)
     if (!job->coef[ci] || job->wblk[ci] <= 0 || job->hblk[ci] <= 0)
       return fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: component %d has no data", ci);
-
   job->up_wblk = job->up_hblk = 0; job->coef_up[0] = job->coef_up[1] = nullptr;
   job->out_hsamp0 = job->hsamp[0]; job->out_vsamp0 = job->vsamp[0];
+  if (*niter < 0) *niter = 0;
+  if (*niter > 100) *niter = 100;                          // reference :2455-2456
+  if (*niter <= 0 && !((flags & QS_UPSAMPLE_UV) && job_needs_lowres(job, flags))) return 0;  // reference :2458
+  return 1;
+}
 
-  int need_lowres = 0;
-  if ((flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV)) && job->colorspace == 3 && job->ncomp >= 3 &&
-      job->hsamp[1] == 1 && job->vsamp[1] == 1 && job->hsamp[2] == 1 && job->vsamp[2] == 1)
-    need_lowres = 1;                                     // reference :2447-2453
-  if (niter < 0) niter = 0;
-  if (niter > 100) niter = 100;                          // reference :2455-2456
-  if (niter <= 0 && !((flags & QS_UPSAMPLE_UV) && need_lowres)) return 0;  // reference :2458
-
+extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int progprec,
+                                     qs_hip_progress_fn progress, void* userdata) {
+  const int todo = prepare_job(job, flags, &niter);
+  if (todo <= 0) return todo;
   if (qs_hip_device_count() <= 0)
     return fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
 
+  if (!progress && job_fusable(job, flags)) {
+    int result = QS_HIP_ENODEV;
+    qs_hip_job* one[1] = { job };
+    if (int r = run_fused(one, std::vector<int>{0}, flags, niter, &result)) return r;
+    return result;
+  }
   int r = run_job(job, flags, niter, progprec, progress, userdata, /*eager=*/progress == nullptr);
   if (r == JOB_RERUN_CAREFUL)
     r = run_job(job, flags, niter, progprec, progress, userdata, /*eager=*/false);
   return r;
+}
+
+extern "C" int qs_hip_do_quantsmooth_batch(qs_hip_job* const* jobs, int njobs, int flags, int niter, int* results) {
+  if (!jobs || !results || njobs < 0) return fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth_batch: null argument");
+  std::vector<int> fused, single;
+  const int nit = niter < 0 ? 0 : niter > 100 ? 100 : niter;     // reference :2455-2456
+  for (int j = 0; j < njobs; ++j) {
+    int n1 = niter;
+    const int todo = prepare_job(jobs[j], flags, &n1);
+    results[j] = todo < 0 ? todo : 0;
+    if (todo <= 0) continue;
+    (job_fusable(jobs[j], flags) ? fused : single).push_back(j);
+  }
+  if (fused.empty() && single.empty()) return QS_HIP_OK;
+  if (qs_hip_device_count() <= 0)
+    return fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+  if (!fused.empty()) {
+    for (int j : fused) results[j] = QS_HIP_ENODEV;
+    const double t0 = wall_ms();
+    const int r = run_fused(jobs, fused, flags, nit, results);
+    if (trace_on()) fprintf(stderr, "qs_hip trace: batch  run_fused total %.2f ms\n", wall_ms() - t0);
+    if (r) return r;
+  }
+  for (int j : single)                                       // coupled / special jobs: the general path, one by one
+    results[j] = qs_hip_do_quantsmooth(jobs[j], flags, niter, 0, nullptr, nullptr);
+  return QS_HIP_OK;
 }

@@ -165,13 +165,10 @@ __device__ __forceinline__ void idct_col_dot2(uint32_t p04, uint32_t p26, uint32
 //   rep_top / rep_bot : write the y = -1 / y = h apron rows by replication
 //             (false for the interior edges of a multi-GPU band, whose apron
 //             rows are halo rows received from the neighbouring band)
-__global__ void __launch_bounds__(256)
-qs_idct_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
-                     uint8_t* __restrict__ plane, int wblk, int hblk, int pitch,
-                     int first, int rep_top, int rep_bot, int* __restrict__ status) {
-  const int nblk = wblk * hblk;
-  const int blk = blockIdx.x * 256 + threadIdx.x;
-  if (blk >= nblk) return;
+__device__ __forceinline__ void
+idct_block_to_plane(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
+                    uint8_t* __restrict__ plane, int wblk, int hblk, int pitch,
+                    int first, int rep_top, int rep_bot, int* __restrict__ status, int blk) {
   const int by = blk / wblk, bx = blk - by * wblk;
 
   uint4* cp = reinterpret_cast<uint4*>(coef) + (size_t)blk * 8;
@@ -232,6 +229,38 @@ qs_idct_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coe
     if (top) *reinterpret_cast<uint2*>(rp - pitch) = pk;
     if (bot) *reinterpret_cast<uint2*>(rp + pitch) = pk;
   }
+}
+
+__global__ void __launch_bounds__(256)
+qs_idct_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
+                     uint8_t* __restrict__ plane, int wblk, int hblk, int pitch,
+                     int first, int rep_top, int rep_bot, int* __restrict__ status) {
+  const int blk = blockIdx.x * 256 + threadIdx.x;
+  if (blk >= wblk * hblk) return;
+  idct_block_to_plane(cst, coef, plane, wblk, hblk, pitch, first, rep_top, rep_bot, status, blk);
+}
+
+// index of the plane that owns 64-block group `w` of a plane-set launch
+// (binary search over the prefix array; everything here is wave-uniform)
+__device__ __forceinline__ int qs_set_find(const QsPlaneSet& set, int w) {
+  int lo = 0, hi = set.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (set.wave0[mid] <= w) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// pass A over a set of planes (whole planes: both apron rows replicated)
+__global__ void __launch_bounds__(256)
+qs_idct_set_kernel(const QsPlaneSet set, int first) {
+  const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (w >= set.wave0[set.n]) return;
+  const int i = qs_set_find(set, w);
+  const QsPlaneRef& r = set.ref[i];
+  const int blk = (w - set.wave0[i]) * 64 + (threadIdx.x & 63);
+  if (blk >= r.wblk * r.hblk) return;
+  idct_block_to_plane(r.cst, r.coef, r.plane, r.wblk, r.hblk, r.pitch, first, 1, 1, r.status, blk);
 }
 
 // --------------------------------------------------------------------------
@@ -373,6 +402,18 @@ __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >
 #undef QS_SMEM_PIPELINE
 #undef QS_SMOOTH_MIN_WAVES
 
+// the same kernel over a set of planes (job / batch layer): parameters come
+// from the plane set in the kernarg segment instead of from scalar arguments
+#define QS_SMOOTH_KERNEL_NAME qs_smooth_set_kernel
+#define QS_SMEM_PIPELINE 1
+#define QS_SMOOTH_MIN_WAVES 3
+#define QS_SMOOTH_SET 1
+#include "qs_smooth_kernel.inc"
+#undef QS_SMOOTH_KERNEL_NAME
+#undef QS_SMEM_PIPELINE
+#undef QS_SMOOTH_MIN_WAVES
+#undef QS_SMOOTH_SET
+
 #define QS_SMOOTH_KERNEL_NAME qs_smooth_plane_kernel_alt
 #define QS_SMEM_PIPELINE 0
 #define QS_SMOOTH_MIN_WAVES 4
@@ -454,6 +495,20 @@ void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* p
   if (alt) { if (diag) QS_GO(qs_smooth_plane_kernel_alt<true>); else QS_GO(qs_smooth_plane_kernel_alt<false>); }
   else     { if (diag) QS_GO(qs_smooth_plane_kernel<true>);     else QS_GO(qs_smooth_plane_kernel<false>); }
 #undef QS_GO
+}
+
+void qs_launch_idct_set(const QsPlaneSet& set, int first, hipStream_t s) {
+  const int nw = set.wave0[set.n];
+  if (nw <= 0) return;
+  hipLaunchKernelGGL(qs_idct_set_kernel, dim3((nw + 3) / 4), dim3(256), 0, s, set, first);
+}
+
+void qs_launch_smooth_set(const QsPlaneSet& set, int diag, int final_clamp, hipStream_t s) {
+  const int nw = set.wave0[set.n];
+  if (nw <= 0) return;
+  const dim3 grid((nw + QS_WAVES_PER_WG - 1) / QS_WAVES_PER_WG), block(64 * QS_WAVES_PER_WG);
+  if (diag) hipLaunchKernelGGL(qs_smooth_set_kernel<true>, grid, block, 0, s, set, final_clamp);
+  else      hipLaunchKernelGGL(qs_smooth_set_kernel<false>, grid, block, 0, s, set, final_clamp);
 }
 
 void qs_launch_clamp(int16_t* coef, size_t nblk, hipStream_t s) {

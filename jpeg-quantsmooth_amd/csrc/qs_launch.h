@@ -9,6 +9,9 @@ void qs_launch_idct_plane(const QsConsts* cst, int16_t* coef, uint8_t* plane, in
                           int first, int rep_top, int rep_bot, int* status, hipStream_t s);
 void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* plane, int wblk, int hblk,
                             int diag, int rebalance, int final_clamp, int blk_begin, int blk_end, hipStream_t s);
+// one launch over a set of whole planes (job / batch layer)
+void qs_launch_idct_set(const QsPlaneSet& set, int first, hipStream_t s);
+void qs_launch_smooth_set(const QsPlaneSet& set, int diag, int final_clamp, hipStream_t s);
 void qs_launch_clamp(int16_t* coef, size_t nblk, hipStream_t s);
 void qs_launch_dequant(const QsConsts* cst, int16_t* coef, size_t nblk, hipStream_t s);
 

@@ -60,11 +60,19 @@ class Job(C.Structure):
     ]
 
 
+class PlaneRef(C.Structure):
+    """qs_hip_plane_ref: one plane of a plane-set launch (device pointers)"""
+    _fields_ = [("d_consts", C.c_void_p), ("d_coef", C.c_void_p), ("d_plane", C.c_void_p), ("d_status", C.c_void_p),
+                ("wblk", C.c_int32), ("hblk", C.c_int32), ("luma", C.c_int32), ("reserved", C.c_int32)]
+
+
+MAX_PLANES = 56
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
 
 # every symbol include/jpegqs_hip.h declares: (restype, argtypes)
 ABI = {
     "qs_hip_do_quantsmooth": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int, C.c_int, PROGRESS_FN, C.c_void_p]),
+    "qs_hip_do_quantsmooth_batch": (C.c_int, [C.POINTER(C.POINTER(Job)), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "qs_hip_free": (None, [C.c_void_p]),
     "qs_hip_release_cache": (None, []),
     "qs_hip_device_count": (C.c_int, []),
@@ -80,6 +88,8 @@ ABI = {
                                       C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_smooth_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_idct_planes": (C.c_int, [C.POINTER(PlaneRef), C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_smooth_planes": (C.c_int, [C.POINTER(PlaneRef), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_joint_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_lowq_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -174,11 +184,8 @@ class HipQS:
         return out
 
     # -- job layer -------------------------------------------------------------
-    def do_quantsmooth(self, coefs, quants, flags, niter, *, hsamp=None, vsamp=None,
-                       colorspace=None, image_size=None, progprec=0, progress=None, threads=None):
-        """Whole do_quantsmooth() on copies of the inputs; same calling convention
-        and result dict as the test oracles (`threads` is accepted and ignored:
-        the GPU has no use for jpegqs_control_t.threads)."""
+    @staticmethod
+    def _make_job(coefs, quants, hsamp=None, vsamp=None, colorspace=None, image_size=None):
         n = len(coefs)
         job = Job()
         job.ncomp = n
@@ -201,8 +208,9 @@ class HipQS:
             mh, mv = max(hsamp), max(vsamp)
             image_size = (work[0].shape[1] * 8 * mh // hsamp[0], work[0].shape[0] * 8 * mv // vsamp[0])
         job.image_width, job.image_height = image_size
-        cb = PROGRESS_FN(progress) if progress else C.cast(None, PROGRESS_FN)
-        ret = self._check(self.lib.qs_hip_do_quantsmooth(C.byref(job), flags, niter, progprec, cb, None))
+        return job, work
+
+    def _job_result(self, job, work, quants, ret):
         up = job.up_wblk > 0
         if up:
             for j in range(2):
@@ -211,9 +219,31 @@ class HipQS:
                 work[1 + j] = np.frombuffer(buf, dtype=np.int16).reshape(job.up_hblk, job.up_wblk, 64).copy()
                 self.lib.qs_hip_free(job.coef_up[j])
         qout = [np.array(job.quant[ci][:], dtype=np.uint16) if quants[ci] is not None else None
-                for ci in range(n)]
+                for ci in range(job.ncomp)]
         return dict(ret=ret, coefs=work, quants=qout, up=up,
                     hsamp0=job.out_hsamp0, vsamp0=job.out_vsamp0)
+
+    def do_quantsmooth(self, coefs, quants, flags, niter, *, hsamp=None, vsamp=None,
+                       colorspace=None, image_size=None, progprec=0, progress=None, threads=None):
+        """Whole do_quantsmooth() on copies of the inputs; same calling convention
+        and result dict as the test oracles (`threads` is accepted and ignored:
+        the GPU has no use for jpegqs_control_t.threads)."""
+        job, work = self._make_job(coefs, quants, hsamp, vsamp, colorspace, image_size)
+        cb = PROGRESS_FN(progress) if progress else C.cast(None, PROGRESS_FN)
+        ret = self._check(self.lib.qs_hip_do_quantsmooth(C.byref(job), flags, niter, progprec, cb, None))
+        return self._job_result(job, work, quants, ret)
+
+    def do_quantsmooth_batch(self, jobs, flags, niter):
+        """qs_hip_do_quantsmooth_batch: `jobs` = list of dicts with the keyword
+        arguments of do_quantsmooth (coefs, quants and optionally hsamp, vsamp,
+        colorspace, image_size) -> list of result dicts in the same order
+        (ret < 0: that job failed with this error code)"""
+        made = [self._make_job(j["coefs"], j["quants"], j.get("hsamp"), j.get("vsamp"),
+                               j.get("colorspace"), j.get("image_size")) for j in jobs]
+        ptrs = (C.POINTER(Job) * len(made))(*[C.pointer(m[0]) for m in made])
+        results = (C.c_int * max(1, len(made)))()
+        self._check(self.lib.qs_hip_do_quantsmooth_batch(ptrs, len(made), flags, niter, results))
+        return [self._job_result(m[0], m[1], j["quants"], int(results[i])) for i, (m, j) in enumerate(zip(made, jobs))]
 
     # -- plane layer (device pointers as ints, stream as int or None) ----------
     def idct_plane(self, d_consts, d_coef, d_plane, wblk, hblk, first, rep_top, rep_bot, d_status, stream=None):
@@ -223,6 +253,21 @@ class HipQS:
     def smooth_plane(self, d_consts, d_coef, d_plane, wblk, hblk, flags, luma=1, final_clamp=0, stream=None):
         self._check(self.lib.qs_hip_smooth_plane(d_consts, d_coef, d_plane, wblk, hblk, flags,
                                                  int(luma), int(final_clamp), stream))
+
+    @staticmethod
+    def plane_refs(planes):
+        """[(d_consts, d_coef, d_plane, d_status, wblk, hblk, luma)] -> ctypes array for the *_planes calls"""
+        arr = (PlaneRef * len(planes))()
+        for r, (cst, coef, plane, status, wb, hb, luma) in zip(arr, planes):
+            r.d_consts, r.d_coef, r.d_plane, r.d_status = cst, coef, plane, status
+            r.wblk, r.hblk, r.luma = wb, hb, int(luma)
+        return arr
+
+    def idct_planes(self, refs, first, stream=None):
+        self._check(self.lib.qs_hip_idct_planes(refs, len(refs), int(first), stream))
+
+    def smooth_planes(self, refs, flags, final_clamp=0, stream=None):
+        self._check(self.lib.qs_hip_smooth_planes(refs, len(refs), flags, int(final_clamp), stream))
 
     def smooth_rows(self, d_consts, d_coef, d_plane, wblk, hblk, row0, row1, flags, luma=1, final_clamp=0, stream=None):
         self._check(self.lib.qs_hip_smooth_rows(d_consts, d_coef, d_plane, wblk, hblk, row0, row1, flags,

@@ -306,3 +306,87 @@ def test_gpu_colour_1080p_every_quality(gpu, oracle, synth, samp):
         a = gpu.do_quantsmooth(j["coefs"], j["quants"], flags, 3, **kw)
         b = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, 3, **kw)
         assert_same_result(a, b, f"1080p {samp} flags={flags}")
+
+
+def test_gpu_plane_set_launch(gpu, oracle, synth):
+    """qs_hip_idct_planes / qs_hip_smooth_planes: planes of different sizes, quant tables
+    and luma/chroma roles in ONE launch per pass == each plane on its own"""
+    import torch
+    dev = torch.device("cuda:0")
+    specs = [(256, 192, 50, 1), (40, 24, 20, 0), (8, 8, 90, 1), (520, 72, 35, 0), (64, 200, 75, 1), (1000, 16, 50, 0)]
+    for flags in (0, 1, 32, 1 | 16):
+        planes, keep, want = [], [], []
+        for k, (w, h, qual, luma) in enumerate(specs):
+            coef, quant = synth.synth_gray(w, h, qual, seed=k)
+            hb, wb = coef.shape[:2]
+            d_coef = torch.from_numpy(coef.copy()).to(dev)
+            d_cst = torch.from_numpy(gpu.consts_build(quant, flags)).to(dev)
+            d_plane = torch.empty(gpu.plane_bytes(wb, hb), dtype=torch.uint8, device=dev)
+            d_status = torch.zeros(1, dtype=torch.int32, device=dev)
+            keep.append((d_coef, d_cst, d_plane, d_status))
+            planes.append((d_cst.data_ptr(), d_coef.data_ptr(), d_plane.data_ptr(), d_status.data_ptr(), wb, hb, luma))
+            # a chroma plane of a YCbCr job: NO_REBALANCE_UV applies; luma: it does not
+            f1 = flags if not luma else flags & ~32
+            f1 = f1 | 16 if (not luma and flags & 32) else f1
+            want.append(oracle.do_quantsmooth([coef], [quant], f1, 2)["coefs"][0])
+        refs = gpu.plane_refs(planes)
+        s = torch.cuda.current_stream().cuda_stream
+        for it in range(2):
+            gpu.idct_planes(refs, it == 0, s)
+            gpu.smooth_planes(refs, flags, it == 1, s)
+        torch.cuda.synchronize()
+        for k, (d_coef, _, _, d_status) in enumerate(keep):
+            assert int(d_status.item()) == 0
+            assert np.array_equal(d_coef.cpu().numpy(), want[k]), f"flags={flags} plane {k}"
+    with pytest.raises(Exception):
+        gpu.smooth_planes(refs, 2, 0, s)                      # coupled flags are not a plane-set matter
+
+
+def _batch_jobs(synth):
+    jobs = []
+    for k, (w, h, qual) in enumerate([(64, 64, 50), (200, 120, 25), (24, 88, 92), (333, 200, 60)]):
+        coef, quant = synth.synth_gray(w, h, qual, seed=k)
+        jobs.append(dict(coefs=[coef], quants=[quant]))
+    for k, (w, h, hs, vs) in enumerate([(141, 93, 2, 2), (72, 40, 1, 1), (96, 64, 2, 1), (321, 240, 2, 2)]):
+        j = synth.synth_ycc(w, h, hs, vs, quality=40 + 10 * k, seed=k)
+        jobs.append(dict(coefs=j["coefs"], quants=j["quants"], hsamp=j["hsamp"], vsamp=j["vsamp"],
+                         colorspace=3, image_size=(w, h)))
+    # special cases inside a batch: range-check failure (careful re-run), all-ones table
+    # (iterations skipped), a table entry >= 0x800 (stop), a zero quantiser
+    coef, quant = synth.synth_gray(64, 64, 50)
+    bad = coef.copy(); bad[3, 4, 0] = 300
+    jobs.append(dict(coefs=[bad], quants=[quant]))
+    jobs.append(dict(coefs=[coef], quants=[np.ones(64, np.uint16)]))
+    qb = quant.copy(); qb[63] = 0x800
+    jobs.append(dict(coefs=[coef], quants=[qb]))
+    qz = quant.copy(); qz[5] = 0
+    jobs.append(dict(coefs=[coef], quants=[qz]))
+    return jobs
+
+
+@pytest.mark.parametrize("flags,niter", [(0, 3), (1, 2), (16, 1), (1 | 32, 2), (7, 2), (9, 1), (0, 0), (4, 0)])
+def test_gpu_batch_equals_single_jobs(gpu, oracle, synth, flags, niter):
+    """qs_hip_do_quantsmooth_batch: independent jobs fused into plane-set launches, coupled /
+    special ones through the general path -- every result as the oracle's for that job alone"""
+    jobs = _batch_jobs(synth)
+    got = gpu.do_quantsmooth_batch(jobs, flags, niter)
+    assert len(got) == len(jobs)
+    for k, (j, a) in enumerate(zip(jobs, got)):
+        kw = {n: j[n] for n in ("hsamp", "vsamp", "colorspace", "image_size") if n in j}
+        b = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+        assert_same_result(a, b, f"batch job {k} flags={flags} niter={niter}")
+
+
+def test_gpu_batch_many_planes_and_empty(gpu, oracle, synth):
+    """more planes than one launch takes (QS_HIP_MAX_PLANES): several groups; empty batch"""
+    assert gpu.do_quantsmooth_batch([], 0, 3) == []
+    jobs = []
+    for k in range(40):
+        j = synth.synth_ycc(48 + 8 * (k % 5), 32 + 8 * (k % 3), 2, 2, quality=50, seed=k)
+        jobs.append(dict(coefs=j["coefs"], quants=j["quants"], hsamp=j["hsamp"], vsamp=j["vsamp"],
+                         colorspace=3, image_size=(48 + 8 * (k % 5), 32 + 8 * (k % 3))))
+    got = gpu.do_quantsmooth_batch(jobs, 1, 2)
+    for k, (j, a) in enumerate(zip(jobs, got)):
+        b = oracle.do_quantsmooth(j["coefs"], j["quants"], 1, 2, hsamp=j["hsamp"], vsamp=j["vsamp"],
+                                  colorspace=3, image_size=j["image_size"])
+        assert_same_result(a, b, f"job {k}")

@@ -45,8 +45,8 @@ libdir = Path(pkg.lib_path()).parent
 subprocess.check_call(["gcc", "-O2", "-o", str(exe), str(ROOT / "tools" / "bench_serving.c"), f"-I{ROOT / 'include'}",
                        f"-L{libdir}", "-ljpegqs_hip", f"-Wl,-rpath,{libdir}", "-lpthread"])
 print(f"# {w}x{h} 4:2:0 --quality {quality} --niter {niter}, {sum(c.shape[0] * c.shape[1] for c in j['coefs'])} blocks per image", flush=True)
-for nthreads in (1, 2, 4, 8, 16, 32):
-    per = max(8, 256 // nthreads)
-    r = subprocess.run([str(exe), str(out / "job.bin"), str(flags), str(niter), str(nthreads), str(per)],
+for nthreads, batch in ((1, 1), (2, 1), (4, 1), (8, 1), (16, 1), (1, 4), (1, 8), (1, 16), (1, 32), (2, 8), (2, 16), (4, 8), (4, 16)):
+    per = max(2 * batch, 256 // nthreads)
+    r = subprocess.run([str(exe), str(out / "job.bin"), str(flags), str(niter), str(nthreads), str(per), str(batch)],
                        capture_output=True, text=True)
     print(r.stdout.strip() or r.stderr.strip(), flush=True)
