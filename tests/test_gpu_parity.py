@@ -390,3 +390,17 @@ def test_gpu_batch_many_planes_and_empty(gpu, oracle, synth):
         b = oracle.do_quantsmooth(j["coefs"], j["quants"], 1, 2, hsamp=j["hsamp"], vsamp=j["vsamp"],
                                   colorspace=3, image_size=j["image_size"])
         assert_same_result(a, b, f"job {k}")
+
+
+def test_gpu_fuzz_corpus():
+    """tests/golden/fuzz_s2.jsonl: 400 seeded trials (959 jobs: every flag combination, sizes up to
+    1400x1050, all chroma layouts, extreme blocks, batches) whose expected output hashes were written
+    by the oracle (`tools/fuzz_gpu.py gen`); the GPU side regenerates the inputs and compares"""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_gpu.py"), "run", str(root / "tests" / "golden" / "fuzz_s2.jsonl")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "400 trials, 959 jobs" in r.stdout and " 0 failures" in r.stdout
