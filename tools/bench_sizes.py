@@ -2,7 +2,7 @@
 """Pass-B launch time against plane height at 8192 px width (1024 blocks per row):
 hblk = 64 rows is one wave per SIMD on the whole chip.  Shows the latency floor
 (a lone wave), the occupancy steps and where the kernel reaches its streaming rate.
-    python tools/bench_sizes.py [flags=0] [lib ...]"""
+    python tools/bench_sizes.py [--flags 0] [--rows 64,128,...] [lib ...]"""
 import sys
 from pathlib import Path
 
@@ -13,13 +13,20 @@ sys.path.insert(0, str(ROOT))
 import jpegqs_pkg  # noqa: E402
 import bench  # noqa: E402
 
+import argparse  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--flags", type=int, default=0)
+ap.add_argument("--rows", default="1,8,16,32,48,64,96,112,128,144,160,192,256,384,512,1024")
+ap.add_argument("libs", nargs="*")
+args = ap.parse_args()
 pkg = jpegqs_pkg.load()
-flags = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-libs = [Path(p) for p in sys.argv[2:]] or [pkg.lib_path()]
+flags = args.flags
+libs = [Path(p) for p in args.libs] or [pkg.lib_path()]
 dev = torch.device("cuda:0")
 full, quant = bench.synth_input_gpu(torch, pkg, 8192, 50, dev)
 wb = 1024
-rows = [1, 8, 16, 32, 48, 64, 96, 112, 128, 144, 160, 192, 256, 384, 512, 1024]
+rows = [int(r) for r in args.rows.split(",")]
 print("flags", flags, "rows:", rows)
 for lib in libs:
     hip = pkg.HipQS(lib)
