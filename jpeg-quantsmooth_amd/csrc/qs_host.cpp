@@ -21,6 +21,7 @@
 #include <mutex>
 #include <vector>
 #include <deque>
+#include <list>
 #include <atomic>
 #include <thread>
 #include <condition_variable>
@@ -487,7 +488,7 @@ struct PinnedBuf {
 };
 
 
-static const size_t kStageMin = (size_t)2 << 20, kStageChunk = (size_t)8 << 20;
+static const size_t kStageMin = (size_t)1 << 20, kStageChunk = (size_t)8 << 20;
 static const int kStageThreads = 4;   // parts per chunk
 static const int kPoolThreads = 8;    // helper threads (several transfers can be in flight)
 
@@ -691,6 +692,8 @@ struct StreamLease {     // borrow a ready-made set of streams, give it back on 
 struct Comp {            // per-component device state (kept until the job ends)
   DevBuf coef, plane, cst, status, up, px;
   PinnedBuf stage;           // pinned upload staging, held until the job's streams are drained
+  PinnedBuf hstatus;         // range-check flag on its way back
+  Download down, down_up;    // results on their way back
   bool processed = false, dequant_only = false, have_up = false;
   hipStream_t stream = nullptr;
 };
@@ -864,31 +867,40 @@ static int run_job(qs_hip_job* job, int flags, int niter, int progprec,
     if (!eager) HIP_TRY(hipStreamSynchronize(s));
   }
 
+  // ---- behind each component's kernels: range-check flag and results into pinned memory
+  const size_t ubytes = (size_t)job->wblk[0] * job->hblk[0] * 64 * sizeof(int16_t);
+  for (int ci = 0; ci < job->ncomp; ++ci) {
+    Comp& C = comp[ci];
+    if (!C.processed) continue;
+    const size_t cbytes = (size_t)job->wblk[ci] * job->hblk[ci] * 64 * sizeof(int16_t);
+    if (eager && !C.dequant_only) {
+      if (!C.hstatus.alloc(sizeof(int32_t))) return fail(QS_HIP_ENOMEM, "out of pinned host memory");
+      HIP_TRY(hipMemcpyAsync(C.hstatus.p, C.status.p, sizeof(int32_t), hipMemcpyDeviceToHost, C.stream));
+    }
+    HIP_TRY(C.down.issue(C.coef.p, cbytes, C.stream));
+    if (C.have_up && !stop) HIP_TRY(C.down_up.issue(C.up.p, ubytes, C.stream));
+  }
+
   // ---- everything is enqueued; eager mode reads the range-check flags now
   const double t_enq = wall_ms();
   for (int i = 0; i < nstreams; ++i) HIP_TRY(hipStreamSynchronize(st.s[i]));
   const double t_done = wall_ms();
   if (eager)
     for (int ci = 0; ci < job->ncomp; ++ci)
-      if (comp[ci].processed && !comp[ci].dequant_only) {
-        int32_t bad = 0;
-        HIP_TRY(hipMemcpy(&bad, comp[ci].status.p, sizeof(bad), hipMemcpyDeviceToHost));
-        if (bad) return JOB_RERUN_CAREFUL;               // host input is still untouched
-      }
+      if (comp[ci].processed && !comp[ci].dequant_only && *static_cast<const int32_t*>(comp[ci].hstatus.p))
+        return JOB_RERUN_CAREFUL;                          // host input is still untouched
 
-  // ---- copy results back (the only place host memory is written)
+  // ---- scatter the results (the only place host memory is written)
   for (int ci = 0; ci < job->ncomp; ++ci) {
     Comp& C = comp[ci];
     if (!C.processed) continue;
     const size_t cbytes = (size_t)job->wblk[ci] * job->hblk[ci] * 64 * sizeof(int16_t);
-    HIP_TRY(hipMemcpyAsync(job->coef[ci], C.coef.p, cbytes, hipMemcpyDeviceToHost, st.s[0]));
+    HIP_TRY(C.down.finish(C.coef.p, std::vector<Piece>{{job->coef[ci], 0, cbytes}}, C.stream));
     if (C.have_up && !stop)
-      HIP_TRY(hipMemcpyAsync(up_host[ci - 1], C.up.p, (size_t)job->wblk[0] * job->hblk[0] * 64 * sizeof(int16_t),
-                             hipMemcpyDeviceToHost, st.s[0]));
+      HIP_TRY(C.down_up.finish(C.up.p, std::vector<Piece>{{up_host[ci - 1], 0, ubytes}}, C.stream));
   }
-  HIP_TRY(hipStreamSynchronize(st.s[0]));
   if (trace_on())
-    fprintf(stderr, "qs_hip trace: %s  enqueue %.2f ms (host->pinned->device issue %.2f)  drain %.2f ms  download %.2f ms\n",
+    fprintf(stderr, "qs_hip trace: %s  enqueue %.2f ms (host->pinned->device issue %.2f)  drain %.2f ms  scatter %.2f ms\n",
             eager ? "eager" : "careful", t_enq - t_start, t_upload, t_done - t_enq, wall_ms() - t_done);
 
   if (!stop && have_yfull && up_host[0] && up_host[1]) {  // reference :2836-2849
@@ -934,7 +946,10 @@ static bool job_fusable(const qs_hip_job* job, int flags) {
   return true;
 }
 
-struct FPlane { int job, ci, wb, hb, cst; size_t coef_off, px_off, cbytes; };
+// One device plane of a set: a whole component, or a band of block rows of a very large
+// one (rows [src_row0, src_row0 + hb) of the source, of which [keep0, keep1) are results:
+// the rest is halo, see split_rows).
+struct FPlane { int job, ci, wb, hb, cst; size_t coef_off, px_off, cbytes; int src_row0, keep0, keep1; };
 struct FGroup {
   std::vector<FPlane> planes;
   std::vector<int> jobs;                  // indices into the caller's job list
@@ -954,19 +969,59 @@ struct DrainGuard {                       // error paths: nothing may be freed w
 // a group of >= 3 waves per SIMD runs at the streaming rate; smaller groups let the upload of one
 // overlap the kernels of the previous and the download of the one before (three streams)
 static const size_t kGroupBlocks = (size_t)200 << 10;
+// A plane above kSplitBlocks is cut into bands of about kBandBlocks that travel as separate
+// groups, so its upload, kernels and download overlap as they do for a batch of small jobs.
+// A block's result after n iterations depends only on blocks within n rows of it, so a band
+// carries n extra block rows on each cut side (recomputed, not copied back): bit-exact.
+// (QS_HIP_SPLIT_BLOCKS / QS_HIP_BAND_BLOCKS override the two sizes: the tests use them to run
+// the band logic on small images.)
+static size_t env_size(const char* name, size_t dflt) {
+  const char* v = getenv(name);
+  const long long n = v ? atoll(v) : 0;
+  return n > 0 ? (size_t)n : dflt;
+}
+static const size_t kSplitBlocks = env_size("QS_HIP_SPLIT_BLOCKS", (size_t)512 << 10),
+                    kBandBlocks = env_size("QS_HIP_BAND_BLOCKS", (size_t)256 << 10);
 
 static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int flags, int niter, int* results) {
   StreamLease lease;
   if (!lease.p) return fail(QS_HIP_ENODEV, "could not create HIP streams: %s", hipGetErrorString(hipGetLastError()));
-  std::deque<FGroup> groups;
+  std::list<FGroup> groups;
   DrainGuard drain{lease.p};
   const double t_start = wall_ms();
 
-  // ---- partition into groups (a job never straddles two)
+  // ---- partition into groups (a job never straddles two, unless it is cut into bands)
+  int maxj = 0;
+  for (int ji : which) maxj = std::max(maxj, ji);
+  std::vector<char> split(maxj + 1, 0), bad_job(maxj + 1, 0), scattered(maxj + 1, 0), defer(maxj + 1, 0);
   for (int ji : which) {
     const qs_hip_job* job = jobs[ji];
     size_t jblocks = 0;
-    for (int ci = 0; ci < job->ncomp; ++ci) jblocks += (size_t)job->wblk[ci] * job->hblk[ci];
+    bool big = false;
+    for (int ci = 0; ci < job->ncomp; ++ci) {
+      const size_t nb = (size_t)job->wblk[ci] * job->hblk[ci];
+      jblocks += nb;
+      const int bands = (int)((nb + kBandBlocks - 1) / kBandBlocks);
+      if (nb > kSplitBlocks && (job->hblk[ci] + bands - 1) / bands >= 8 * niter) big = true;   // halo <= 25 %
+    }
+    if (big) {
+      split[ji] = 1;
+      for (int ci = 0; ci < job->ncomp; ++ci) {
+        const int wb = job->wblk[ci], hb = job->hblk[ci];
+        const int bands = std::max(1, (int)(((size_t)wb * hb + kBandBlocks - 1) / kBandBlocks));
+        const int rows = (hb + bands - 1) / bands;
+        for (int r0 = 0; r0 < hb; r0 += rows) {
+          const int r1 = std::min(hb, r0 + rows), d0 = std::max(0, r0 - niter), d1 = std::min(hb, r1 + niter);
+          groups.emplace_back();
+          FGroup& G = groups.back();
+          G.jobs.push_back(ji);
+          G.blocks = (size_t)wb * (d1 - d0);
+          G.planes.push_back({ji, ci, wb, d1 - d0, -1, 0, 0, (size_t)wb * (d1 - d0) * 128, d0, r0 - d0, r1 - d0});
+        }
+      }
+      groups.emplace_back();                                 // the next job starts a fresh group
+      continue;
+    }
     if (groups.empty() || (int)groups.back().planes.size() + job->ncomp > QS_MAX_PLANES ||
         (groups.back().blocks && groups.back().blocks + jblocks > kGroupBlocks))
       groups.emplace_back();
@@ -974,14 +1029,16 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
     G.jobs.push_back(ji);
     G.blocks += jblocks;
     for (int ci = 0; ci < job->ncomp; ++ci)
-      G.planes.push_back({ji, ci, job->wblk[ci], job->hblk[ci], -1, 0, 0, (size_t)job->wblk[ci] * job->hblk[ci] * 128});
+      G.planes.push_back({ji, ci, job->wblk[ci], job->hblk[ci], -1, 0, 0, (size_t)job->wblk[ci] * job->hblk[ci] * 128,
+                          0, 0, job->hblk[ci]});
   }
+  groups.remove_if([](const FGroup& g) { return g.planes.empty(); });   // placeholders left by band jobs
 
   // ---- enqueue every group: upload, niter x (pass A, pass B), status readback
   const int diag = (flags & QS_DIAGONALS) != 0;
-  for (size_t gi = 0; gi < groups.size(); ++gi) {
-    FGroup& G = groups[gi];
-    G.s = lease.p->s[gi % 3];
+  size_t gi = 0;
+  for (FGroup& G : groups) {
+    G.s = lease.p->s[gi++ % 3];
     const int np = (int)G.planes.size();
     size_t coef_bytes = 0, px_bytes = 0;
     std::vector<const uint16_t*> qtabs;
@@ -1002,7 +1059,8 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
       if (int r = qs_hip_consts_build(&G.hc[k], qtabs[k], flags)) return r;
     HIP_TRY(hipMemcpyAsync(G.cst.p, G.hc.data(), qtabs.size() * sizeof(QsConsts), hipMemcpyHostToDevice, G.s));
     std::vector<Piece> pieces;
-    for (const FPlane& P : G.planes) pieces.push_back({jobs[P.job]->coef[P.ci], P.coef_off, P.cbytes});
+    for (const FPlane& P : G.planes)
+      pieces.push_back({jobs[P.job]->coef[P.ci] + (size_t)P.src_row0 * P.wb * 64, P.coef_off, P.cbytes});
     G.coef_bytes = coef_bytes;
     HIP_TRY(upload_pieces(G.coef.p, pieces, coef_bytes, G.s, G.stage));
     HIP_TRY(hipMemsetAsync(G.status.p, 0, (size_t)np * sizeof(int32_t), G.s));
@@ -1036,29 +1094,54 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
   }
   const double t_enq = wall_ms();
 
-  // ---- drain group by group; results go back only for jobs whose range check passed
-  std::vector<int> rerun;
+  // ---- drain group by group; results go back only for jobs whose range check passed.
+  // A job cut into bands is scattered band by band before its later bands have been
+  // checked: should one of those trip the range check after all (crafted file), the rows
+  // already written are restored from the pinned upload staging, which still holds the
+  // original input.  Without that staging copy (pinned memory exhausted) the job's bands
+  // are held back until all of them have been checked.
+  auto result_piece = [&](const FPlane& P) {
+    const size_t row = (size_t)P.wb * 128;
+    return Piece{jobs[P.job]->coef[P.ci] + (size_t)(P.src_row0 + P.keep0) * P.wb * 64,
+                 P.coef_off + P.keep0 * row, (size_t)(P.keep1 - P.keep0) * row};
+  };
+  for (FGroup& G : groups)
+    if (!G.stage.p) for (int ji : G.jobs) if (split[ji]) defer[ji] = 1;
+  std::vector<FGroup*> held;
   for (FGroup& G : groups) {
     HIP_TRY(G.down.wait_first(G.s));
     const int32_t* hst = static_cast<const int32_t*>(G.hstatus.p);
+    for (size_t i = 0; i < G.planes.size(); ++i) if (hst[i]) bad_job[G.planes[i].job] = 1;
+    bool hold = false;
+    for (int ji : G.jobs) hold |= (defer[ji] != 0);
+    if (hold) { held.push_back(&G); continue; }
     std::vector<Piece> back;
-    for (int ji : G.jobs) {
-      bool bad = false;
-      for (size_t i = 0; i < G.planes.size(); ++i) if (G.planes[i].job == ji && hst[i]) bad = true;
-      if (bad) { rerun.push_back(ji); continue; }           // host input is still untouched
-      for (const FPlane& P : G.planes)
-        if (P.job == ji) back.push_back({jobs[ji]->coef[P.ci], P.coef_off, P.cbytes});
-      results[ji] = 0;
-    }
+    for (const FPlane& P : G.planes)
+      if (!bad_job[P.job]) { back.push_back(result_piece(P)); scattered[P.job] = 1; }
     HIP_TRY(G.down.finish(G.coef.p, back, G.s));
+  }
+  for (FGroup* G : held) {
+    std::vector<Piece> back;
+    for (const FPlane& P : G->planes) if (!bad_job[P.job]) back.push_back(result_piece(P));
+    HIP_TRY(G->down.finish(G->coef.p, back, G->s));
+  }
+  std::vector<int> rerun;
+  for (int ji : which) {
+    if (!bad_job[ji]) { results[ji] = 0; continue; }
+    rerun.push_back(ji);
+    if (!scattered[ji]) continue;                            // host input is still untouched
+    for (FGroup& G : groups)                                 // put the original rows back
+      for (const FPlane& P : G.planes)
+        if (P.job == ji && G.stage.p) {
+          const Piece pc = result_piece(P);
+          memcpy(pc.host, static_cast<const char*>(G.stage.p) + pc.off, pc.len);
+        }
   }
   if (trace_on())
     fprintf(stderr, "qs_hip trace: fused  %zu job(s) in %zu group(s)  enqueue %.2f ms  drain+download %.2f ms  (%zu re-run)\n",
             which.size(), groups.size(), t_enq - t_start, wall_ms() - t_enq, rerun.size());
   for (int ji : which) {
-    bool again = false;
-    for (int r : rerun) again |= (r == ji);
-    if (again) continue;
+    if (bad_job[ji]) continue;
     for (int ci = 0; ci < jobs[ji]->ncomp; ++ci)           // reference :2851-2859
       for (int i = 0; i < 64; ++i) jobs[ji]->quant[ci][i] = 1;
   }

@@ -404,3 +404,55 @@ def test_gpu_fuzz_corpus():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "400 trials, 959 jobs" in r.stdout and " 0 failures" in r.stdout
+
+
+def _run_py(code, env_extra, timeout=900):
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout, cwd=str(root), env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+_BAND_ENV = {"QS_HIP_SPLIT_BLOCKS": "60", "QS_HIP_BAND_BLOCKS": "40"}
+
+
+def test_gpu_banded_planes_fuzz_corpus():
+    """the job layer cuts very large planes into bands with niter halo rows (upload, kernels and
+    download of the bands overlap); with the two size thresholds lowered through the environment
+    the same code runs on every plane of the committed corpus -- results must not change"""
+    out = _run_py("import runpy, sys; sys.argv = ['fuzz_gpu.py', 'run', 'tests/golden/fuzz_s2.jsonl']; "
+                  "runpy.run_path('tools/fuzz_gpu.py', run_name='__main__')", _BAND_ENV)
+    assert "400 trials, 959 jobs" in out and " 0 failures" in out
+
+
+def test_gpu_banded_plane_range_check_trips_late():
+    """a bad coefficient in the LAST band of a banded job: earlier bands have already been written
+    back when it is found; they must be restored and the job re-run in the careful order, giving the
+    reference's stop semantics -- also inside a batch next to healthy jobs"""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+import jpegqs_pkg
+from oracle.oracle import Oracle
+from helpers import assert_same_result
+pkg = jpegqs_pkg.load(); hip = pkg.HipQS(); O = Oracle()
+coef, quant = pkg.synth.synth_gray(64, 512, 50, seed=3)          # 8 x 64 blocks -> 13 bands of <= 5 rows + halo
+bad = coef.copy(); bad[60, 2, 0] = 300                           # 300 * 16 > 0x7ff, in the last band
+good, q2 = pkg.synth.synth_gray(96, 200, 60, seed=4)
+for flags, niter in ((0, 3), (1, 2)):
+    a = hip.do_quantsmooth([bad], [quant], flags, niter)
+    b = O.do_quantsmooth([bad], [quant], flags, niter)
+    assert b["ret"] == 1
+    assert_same_result(a, b, f"single flags={flags}")
+    jobs = [dict(coefs=[good], quants=[q2]), dict(coefs=[bad], quants=[quant]), dict(coefs=[coef], quants=[quant])]
+    got = hip.do_quantsmooth_batch(jobs, flags, niter)
+    for j, g in zip(jobs, got):
+        assert_same_result(g, O.do_quantsmooth(j["coefs"], j["quants"], flags, niter), f"batch flags={flags}")
+print("ok")
+'''
+    assert "ok" in _run_py(code, _BAND_ENV)
