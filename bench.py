@@ -144,10 +144,22 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_note = None
     if world > 1:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)                      # brings RCCL up (or fails) before anything is timed
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            except Exception as e:                          # noqa: BLE001 -- report a number rather than none
+                comm_note = f"RCCL unavailable ({type(e).__name__}: {str(e)[:120]}); halo rows staged through the host over gloo"
+                print(f"bench.py rank {rank}: {comm_note}", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                args.backend = "gloo"
+        if args.backend != "nccl":
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = jpegqs_pkg.load()
@@ -270,10 +282,11 @@ def main():
             "mpixels_per_s": value * 64 / 1e6,
             "config": {"workload": f"{size}x{size} luma plane ({hblk_total * wblk} blocks), jpegqs --quality {args.quality} "
                                    f"(flags={flags}) --niter {args.niter}, synthetic JPEG-quality-{args.jpeg_quality} coefficients",
-                       "sharding": "none" if world == 1 else f"{world} block-row bands, 1-pixel-row halo over RCCL per iteration, "
+                       "sharding": "none" if world == 1 else f"{world} block-row bands, 1-pixel-row halo over "
+                                                               f"{'RCCL' if args.backend == 'nccl' else 'gloo (host-staged)'} per iteration, "
                                                                + ("exchange overlapped with the interior rows" if args.overlap
                                                                   else "exchange between pass A and pass B in stream order"),
-                       "blocks_per_gpu": band_blocks},
+                       "blocks_per_gpu": band_blocks, **({"comm_note": comm_note} if comm_note else {})},
             "roofline": {"bound": "hbm", "kernel": "qs_smooth_plane_kernel", "achieved": achieved_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kern_ms,

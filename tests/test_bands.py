@@ -178,7 +178,7 @@ def test_plane_rows_exchange_gloo(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--overlap"]])
+@pytest.mark.parametrize("extra", [[], ["--overlap"], ["--backend", "nccl"]])
 def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one
     process per rank, band split, comm side stream, overlapped schedule), but on ONE
@@ -190,9 +190,13 @@ def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
            "--size", "1024", "--steps", "2", "--warmup", "1", "--verify", "--no-cpu-baseline", *extra]
+    # (the "--backend nccl" case: two ranks on one device is something RCCL refuses, which exercises the
+    # labelled fall-back to host-staged halo rows -- the path a multi-GPU node without working RCCL would take)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["verify_band_edges_ok"] is True and d["verify_ok"] is True
+    if "nccl" in extra:
+        assert "RCCL unavailable" in d["config"]["comm_note"] and "gloo" in d["config"]["sharding"]
