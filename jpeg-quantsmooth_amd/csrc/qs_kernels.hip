@@ -52,14 +52,20 @@ __device__ __forceinline__ uint32_t mulc(uint32_t a, int c) {
 
 // 1-D LL&M inverse DCT butterfly, 13-bit constants, wrapping int32 arithmetic.
 // Behaviour of reference idct.h:57-89.
-__device__ __forceinline__ void idct8(uint32_t (&v)[8]) {
+// `bias` (the rounding constant of the descale that follows, plus the level shift
+// in pass 2) enters through the two DC terms, from where it reaches all eight
+// outputs exactly once: two adds instead of eight (integer ring arithmetic).
+#ifndef QS_IDCT_FOLD_BIAS
+#define QS_IDCT_FOLD_BIAS 1
+#endif
+__device__ __forceinline__ void idct8(uint32_t (&v)[8], uint32_t bias) {
   uint32_t z1, z2, z3, z4, z5, t0, t1, t2, t3, e0, e1, e2, e3;
   z2 = v[2]; z3 = v[6];
   z1 = mulc(z2 + z3, 4433);
   t2 = z1 - mulc(z3, 15137);
   t3 = z1 + mulc(z2, 6270);
-  t0 = (v[0] + v[4]) << 13;
-  t1 = (v[0] - v[4]) << 13;
+  t0 = ((v[0] + v[4]) << 13) + bias;
+  t1 = ((v[0] - v[4]) << 13) + bias;
   e0 = t0 + t3; e3 = t0 - t3; e1 = t1 + t2; e2 = t1 - t2;
   t0 = v[7]; t1 = v[5]; t2 = v[3]; t3 = v[1];
   z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; z4 = t1 + t3;
@@ -84,16 +90,26 @@ __device__ __forceinline__ void idct_pass1(uint32_t (&ws)[64]) {
     uint32_t col[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) col[j] = ws[j * 8 + x];
-    idct8(col);
+#if QS_IDCT_FOLD_BIAS
+    idct8(col, 1024u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ws[j * 8 + x] = (uint32_t)((int32_t)col[j] >> 11);
+#else
+    idct8(col, 0u);
 #pragma unroll
     for (int j = 0; j < 8; ++j) ws[j * 8 + x] = (uint32_t)((int32_t)(col[j] + 1024u) >> 11);
+#endif
   }
 }
 
 // pass 2 for one row; folds +128 and rounding, clamps to 0..255
 // (reference idct.h:509-538).
 __device__ __forceinline__ void idct_pass2_row(uint32_t (&row)[8], int (&out)[8]) {
-  idct8(row);
+#if QS_IDCT_FOLD_BIAS
+  idct8(row, 257u << 17);
+#else
+  idct8(row, 0u);
+#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     // clamp BEFORE the shift (same result as clamping (x >> 18) to 0..255).
@@ -102,10 +118,59 @@ __device__ __forceinline__ void idct_pass2_row(uint32_t (&row)[8], int (&out)[8]
     // bytes into bits 31:16 of its result as if they were zero -- they are
     // not on MI355X (observed: corrupted pixels 6/7 of every row).  Clamping
     // first keeps that instruction out; csrc/Makefile greps the ISA for it.
+#if QS_IDCT_FOLD_BIAS
+    int z = (int32_t)row[j];
+#else
     int z = (int32_t)(row[j] + (257u << 17));
+#endif
     z = min(max(z, 0), (256 << 18) - 1);
     out[j] = z >> 18;
   }
+}
+
+// The recovery kernel keeps pixels as floats.  Only DIFFERENCES of pixels are
+// ever used (QS_TERM), so a pixel p is stored as 2^11 + p * 2^-12 -- the float
+// whose bit pattern is 0x45000000 | p (one ulp there is 2^-12): differences of
+// two such floats are exact and equal (pa - pb) * 2^-12, what the scaled term
+// arithmetic expects, and building one costs a single v_alignbit_b32 on the
+// clamped pass-2 value (or one SDWA v_or on a packed neighbour byte) instead
+// of shift + convert + multiply.  QS_PIX_MAGIC=0 keeps the plain p * 2^-12 form.
+#ifndef QS_PIX_MAGIC
+#define QS_PIX_MAGIC 1
+#endif
+#define QS_PIX_BITS 0x45000000u
+__device__ __forceinline__ void idct_pass2_row_f(uint32_t (&row)[8], float (&out)[8]) {
+#if QS_PIX_MAGIC
+#if QS_IDCT_FOLD_BIAS
+  idct8(row, 257u << 17);
+#else
+  idct8(row, 0u);
+#endif
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#if QS_IDCT_FOLD_BIAS
+    int z = (int32_t)row[j];
+#else
+    int z = (int32_t)(row[j] + (257u << 17));
+#endif
+    z = min(max(z, 0), (256 << 18) - 1);
+    // {0x11400 : z} >> 18  =  (0x11400 << 14) | (z >> 18)  =  0x45000000 | pixel
+    out[j] = __builtin_bit_cast(float, __builtin_amdgcn_alignbit(QS_PIX_BITS >> 14, (uint32_t)z, 18));
+  }
+#else
+  int o[8];
+  idct_pass2_row(row, o);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = (float)o[j] * 0.000244140625f;
+#endif
+}
+// byte n of a packed word of neighbour pixels, in the same representation
+__device__ __forceinline__ float pix_from_byte(uint32_t v, int n) {
+#if QS_PIX_MAGIC
+  return __builtin_bit_cast(float, QS_PIX_BITS | ((v >> (8 * n)) & 0xffu));
+#else
+  return (float)((v >> (8 * n)) & 0xffu) * 0.000244140625f;
+#endif
 }
 
 // --------------------------------------------------------------------------
