@@ -22,7 +22,7 @@ enum {
   QS_NO_REBALANCE = 16, QS_NO_REBALANCE_UV = 32, QS_TRANSCODE = 64
 };
 
-// Per-component constants, built on the host (qs_host.cpp) and read through
+// Per-component constants, built on the host (qs_tables.cpp) and read through
 // the scalar cache: every lane of a wave works on the same coefficient index,
 // so all of this is wave-uniform.
 struct QsConsts {

@@ -1,0 +1,570 @@
+// qs_job.cpp -- job layer of the flat C ABI (include/jpegqs_hip.h): the host-side
+// semantics of the reference's plane driver (reference quantsmooth.h:2404-2878) --
+// validation, early-outs, iteration loop with progress/cancel between launches, final
+// clamp, quant tables := 1 -- with the per-plane passes running as gfx950 kernels.
+// No CPU compute fallback exists.
+#include <list>
+#include <chrono>
+
+#include "qs_xfer.h"
+
+// ---------------------------------------------------------------------------
+// job layer
+//
+// Two execution modes share one component routine:
+//  * careful  -- the reference's order: one component after the other, host
+//                sync after the first pass A of each (bad-coefficient stop,
+//                reference :2610) and after every iteration that reports
+//                progress.  Used whenever a progress callback is installed, and
+//                as the re-run path below.
+//  * eager    -- no callback: every component is enqueued without host syncs,
+//                independent components on their own HIP streams ("one
+//                component per stream", BASELINE config 1; chroma waits for
+//                luma through an event when JOINT_YUV/UPSAMPLE_UV couple them).
+//                The range-check flags are read once at the end; nothing is
+//                copied back before that.  If any flag is set (crafted or
+//                damaged file) the job is simply re-run in careful mode from
+//                the untouched host input, which reproduces the reference's
+//                stop semantics exactly.
+// Device buffers come from a small process-wide cache (hipMalloc/hipFree of
+// 100+ MiB cost milliseconds each); qs_hip_release_cache() empties it.
+
+namespace {
+
+struct Comp {            // per-component device state (kept until the job ends)
+  DevBuf coef, plane, cst, status, up, px;
+  PinnedBuf stage;           // pinned upload staging, held until the job's streams are drained
+  PinnedBuf hstatus;         // range-check flag on its way back
+  Download down, down_up;    // results on their way back
+  bool processed = false, dequant_only = false, have_up = false;
+  hipStream_t stream = nullptr;
+};
+
+enum { JOB_RERUN_CAREFUL = -1000 };
+
+static double wall_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static bool trace_on() { static const bool on = getenv("QS_HIP_TRACE") != nullptr; return on; }
+
+static int run_job(qs_hip_job* job, int flags, int niter, int progprec,
+                   qs_hip_progress_fn progress, void* userdata, bool eager) {
+  int need_lowres = 0, stop = 0;
+  if ((flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV)) && job->colorspace == 3 && job->ncomp >= 3 &&
+      job->hsamp[1] == 1 && job->vsamp[1] == 1 && job->hsamp[2] == 1 && job->vsamp[2] == 1)
+    need_lowres = 1;                                     // reference :2447-2453
+
+  // streams/events are pooled too (creating three streams costs ~1 ms)
+  StreamLease lease;
+  if (!lease.p) return qs_fail(QS_HIP_ENODEV, "could not create HIP streams: %s", hipGetErrorString(hipGetLastError()));
+  Streams& st = *lease.p;
+  const int nstreams = eager ? 3 : 1;
+
+  int prog_next = 0, prog_max = 0, prog_thr = 0;
+  if (progress) {                                        // reference :2474-2482
+    for (int ci = 0; ci < job->ncomp; ++ci) prog_max += job->hblk[ci] * job->vsamp[ci] * niter;
+    if (progprec == 0) progprec = 20;
+    if (progprec < 0) progprec = prog_max;
+    prog_thr = (int)((unsigned)(prog_max + progprec - 1) / (unsigned)progprec);
+  }
+
+  QsConsts* hc = new (std::nothrow) QsConsts[QS_HIP_MAXC];   // one per component: uploads are async
+  if (!hc) return qs_fail(QS_HIP_ENOMEM, "out of host memory");
+  struct HcFree { QsConsts* p; ~HcFree() { delete[] p; } } hc_free{hc};
+
+  const double t_start = wall_ms();
+  double t_upload = 0;
+  Comp comp[QS_HIP_MAXC];
+  // planes that outlive their component (reference image1 / image2, :2753-2815)
+  DevBuf d_yfull, d_llow;          // full-res luma plane; luma at chroma resolution
+  bool have_yfull = false, have_llow = false;
+  int16_t* up_host[2] = { nullptr, nullptr };
+  struct UpFree { int16_t** p; bool keep; ~UpFree() { if (!keep) { free(p[0]); free(p[1]); } } } up_free{up_host, false};
+
+  for (int ci = 0; ci < job->ncomp; ++ci) {
+    Comp& C = comp[ci];
+    const int wb = job->wblk[ci], hb = job->hblk[ci];
+    const size_t nblk = (size_t)wb * hb, cbytes = nblk * 64 * sizeof(int16_t);
+    int iters = niter, extra = 0;
+    int prog_cur = prog_next;
+    const int prog_inc = job->vsamp[ci];
+    const int luma = !ci || job->colorspace != 3;        // reference :2639
+    prog_next += hb * prog_inc * niter;
+    if (!job->has_quant[ci]) continue;                   // reference :2493
+    if (have_yfull || (!ci && need_lowres)) extra = 1;   // reference :2495
+
+    int acc = 0;
+    for (int i = 0; i < 64; ++i) acc |= job->quant[ci][i];
+    if (acc <= 1) iters = 0;                             // reference :2501
+    if (acc >= 0x800) stop = 1;                          // reference :2504
+    if (iters + extra == 0) continue;                    // reference :2542
+
+    // stream: luma (and anything coupled to it) on stream 0; independent
+    // components round-robin
+    hipStream_t s = st.s[eager ? ci % nstreams : 0];
+    C.stream = s; C.processed = true;
+    HIP_TRY(C.coef.alloc(cbytes));
+    HIP_TRY(C.cst.alloc(sizeof(QsConsts)));
+    HIP_TRY(C.status.alloc(sizeof(int32_t)));
+    if (int r = qs_hip_consts_build(&hc[ci], job->quant[ci], flags)) return r;
+    HIP_TRY(hipMemcpyAsync(C.cst.p, &hc[ci], sizeof(QsConsts), hipMemcpyHostToDevice, s));
+    { const double t0 = wall_ms(); HIP_TRY(upload(C.coef.p, job->coef[ci], cbytes, s, C.stage)); t_upload += wall_ms() - t0; }
+    HIP_TRY(hipMemsetAsync(C.status.p, 0, sizeof(int32_t), s));
+
+    bool have_plane = false;
+    if (!stop) {
+      // the reference falls back to dequantise-only when the plane cannot be
+      // allocated (reference :2551-2566); same here for device memory
+      hipError_t e = C.plane.alloc(qs_hip_plane_bytes(wb, hb));
+      if (e == hipSuccess) have_plane = true; else (void)hipGetLastError();
+    }
+    if (!have_plane) {
+      C.dequant_only = true;
+      if (int r = qs_hip_dequant_plane(C.cst.p, C.coef.as<int16_t>(), wb, hb, s)) return r;
+      continue;
+    }
+    if (eager && ci > 0 && (have_llow || have_yfull))    // chroma reads planes produced on the luma stream
+      HIP_TRY(hipStreamWaitEvent(s, st.luma_done, 0));
+
+    const int rebalance = !(flags & QS_NO_REBALANCE) && (luma || !(flags & QS_NO_REBALANCE_UV));  // :1567-1568
+    // JOINT_YUV acts through the low-res luma plane only (reference :2636)
+    const bool joint = have_llow && (flags & QS_JOINT_YUV);
+    const int plane_flags = flags & (QS_DIAGONALS | QS_NO_REBALANCE | QS_NO_REBALANCE_UV);
+    bool clamped = false;
+    for (int it = 0; it < iters + extra; ++it) {
+      if (int r = qs_hip_idct_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), wb, hb,
+                                    it == 0, 1, 1, C.status.as<int32_t>(), s)) return r;
+      if (it == 0 && !eager) {                           // reference :2610
+        int32_t bad = 0;
+        HIP_TRY(hipMemcpyAsync(&bad, C.status.p, sizeof(bad), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (bad) { stop = 1; break; }
+      }
+      if (it == iters) break;                            // refresh-only pass, reference :2622
+      // pass B.  The +-1023 clamp rides on the last launch of the last iteration --
+      // unless a refresh-only pass A follows: the reference clamps after its loop
+      // (:2668-2689), so that refresh (the planes JOINT_YUV / UPSAMPLE_UV read) is the
+      // IDCT of the unclamped coefficients.
+      const int last = (it == iters - 1) && !extra;
+      if (flags & QS_LOW_QUALITY) {                      // reference :924-938: never reaches the k-loop
+        if (joint) {
+          if (int r = qs_hip_joint_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), d_llow.as<uint8_t>(),
+                                         wb, hb, rebalance, last, s)) return r;
+        } else {
+          if (int r = qs_hip_lowq_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), wb, hb,
+                                        rebalance, last, s)) return r;
+        }
+      } else {
+        if (joint)
+          if (int r = qs_hip_joint_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), d_llow.as<uint8_t>(),
+                                         wb, hb, 0, 0, s)) return r;
+        if (int r = qs_hip_smooth_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), wb, hb,
+                                        plane_flags, luma, last, s)) return r;
+      }
+      if (last) clamped = true;
+      if (progress) {                                    // reference :2656-2664
+        int cur = prog_cur += hb * prog_inc;
+        if (cur >= prog_thr) {
+          cur = (int)((long long)progprec * cur / prog_max);
+          prog_thr = (int)(((long long)(cur + 1) * prog_max + progprec - 1) / progprec);
+          HIP_TRY(hipStreamSynchronize(s));              // the pass is done when we report it
+          stop = progress(userdata, cur, progprec);
+        }
+        if (stop) break;
+      }
+    }
+    if (!clamped)                                        // reference :2668-2689
+      if (int r = qs_hip_clamp_plane(C.coef.as<int16_t>(), wb, hb, s)) return r;
+
+    if (!stop && have_yfull) {
+      // UPSAMPLE_UV: chroma -> luma resolution, re-encoded (reference :2691-2752)
+      const int ws = job->hsamp[0], hs = job->vsamp[0];
+      const int uwb = job->wblk[0], uhb = job->hblk[0];
+      const size_t ubytes = (size_t)uwb * uhb * 64 * sizeof(int16_t);
+      HIP_TRY(C.px.alloc(qs_hip_upsample_bytes(job->image_width, job->image_height, ws, hs)));
+      HIP_TRY(C.up.alloc(ubytes));
+      up_host[ci - 1] = static_cast<int16_t*>(malloc(ubytes));
+      if (!up_host[ci - 1]) return qs_fail(QS_HIP_ENOMEM, "out of host memory");
+      if (int r = qs_hip_upsample_plane(C.plane.as<uint8_t>(), d_llow.as<uint8_t>(), wb, d_yfull.as<uint8_t>(),
+                                        uwb, uhb, C.px.as<uint8_t>(), job->image_width, job->image_height,
+                                        ws, hs, s)) return r;
+      if (int r = qs_hip_fdct_plane(C.px.as<uint8_t>(), qs_hip_upsample_pitch(job->image_width, ws),
+                                    C.up.as<int16_t>(), uwb, uhb, s)) return r;
+      C.have_up = true;
+    } else if (!stop && !ci && need_lowres) {
+      // keep luma for the chroma passes (reference :2753-2815)
+      const int ws = job->hsamp[0], hs = job->vsamp[0];
+      if (ws == 1 && hs == 1) {
+        d_llow.take(C.plane); have_llow = true;          // image2 = image
+      } else {
+        DevBuf d_l;
+        HIP_TRY(d_l.alloc(qs_hip_plane_bytes(job->wblk[1], job->hblk[1])));
+        if (int r = qs_hip_downsample_plane(C.plane.as<uint8_t>(), wb, hb, d_l.as<uint8_t>(),
+                                            job->wblk[1], job->hblk[1], ws, hs, s)) return r;
+        d_llow.take(d_l); have_llow = true;
+        if (flags & QS_UPSAMPLE_UV) { d_yfull.take(C.plane); have_yfull = true; }   // image1 = image
+      }
+      HIP_TRY(hipEventRecord(st.luma_done, s));
+    }
+    if (!eager) HIP_TRY(hipStreamSynchronize(s));
+  }
+
+  // ---- behind each component's kernels: range-check flag and results into pinned memory
+  const size_t ubytes = (size_t)job->wblk[0] * job->hblk[0] * 64 * sizeof(int16_t);
+  for (int ci = 0; ci < job->ncomp; ++ci) {
+    Comp& C = comp[ci];
+    if (!C.processed) continue;
+    const size_t cbytes = (size_t)job->wblk[ci] * job->hblk[ci] * 64 * sizeof(int16_t);
+    if (eager && !C.dequant_only) {
+      if (!C.hstatus.alloc(sizeof(int32_t))) return qs_fail(QS_HIP_ENOMEM, "out of pinned host memory");
+      HIP_TRY(hipMemcpyAsync(C.hstatus.p, C.status.p, sizeof(int32_t), hipMemcpyDeviceToHost, C.stream));
+    }
+    HIP_TRY(C.down.issue(C.coef.p, cbytes, C.stream));
+    if (C.have_up && !stop) HIP_TRY(C.down_up.issue(C.up.p, ubytes, C.stream));
+  }
+
+  // ---- everything is enqueued; eager mode reads the range-check flags now
+  const double t_enq = wall_ms();
+  for (int i = 0; i < nstreams; ++i) HIP_TRY(hipStreamSynchronize(st.s[i]));
+  const double t_done = wall_ms();
+  if (eager)
+    for (int ci = 0; ci < job->ncomp; ++ci)
+      if (comp[ci].processed && !comp[ci].dequant_only && *static_cast<const int32_t*>(comp[ci].hstatus.p))
+        return JOB_RERUN_CAREFUL;                          // host input is still untouched
+
+  // ---- scatter the results (the only place host memory is written)
+  for (int ci = 0; ci < job->ncomp; ++ci) {
+    Comp& C = comp[ci];
+    if (!C.processed) continue;
+    const size_t cbytes = (size_t)job->wblk[ci] * job->hblk[ci] * 64 * sizeof(int16_t);
+    HIP_TRY(C.down.finish(C.coef.p, std::vector<Piece>{{job->coef[ci], 0, cbytes}}, C.stream));
+    if (C.have_up && !stop)
+      HIP_TRY(C.down_up.finish(C.up.p, std::vector<Piece>{{up_host[ci - 1], 0, ubytes}}, C.stream));
+  }
+  if (trace_on())
+    fprintf(stderr, "qs_hip trace: %s  enqueue %.2f ms (host->pinned->device issue %.2f)  drain %.2f ms  scatter %.2f ms\n",
+            eager ? "eager" : "careful", t_enq - t_start, t_upload, t_done - t_enq, wall_ms() - t_done);
+
+  if (!stop && have_yfull && up_host[0] && up_host[1]) {  // reference :2836-2849
+    job->coef_up[0] = up_host[0]; job->coef_up[1] = up_host[1]; up_free.keep = true;
+    job->up_wblk = job->wblk[0]; job->up_hblk = job->hblk[0];
+    job->out_hsamp0 = job->out_vsamp0 = 1;
+  }
+  for (int ci = 0; ci < job->ncomp; ++ci)                // reference :2851-2859
+    if (job->has_quant[ci]) for (int i = 0; i < 64; ++i) job->quant[ci][i] = 1;
+  return stop;
+}
+
+
+// ---------------------------------------------------------------------------
+// fused execution: jobs whose components are independent of each other (no
+// JOINT_YUV / UPSAMPLE_UV coupling, no LOW_QUALITY, ordinary quant tables) run
+// as plane sets -- ONE pass-A and ONE pass-B launch per iteration for all
+// components of all jobs of a group (qs_*_set_kernel), so that small images
+// fill the chip together and a job does not occupy three hardware queues.
+// Everything else about the job semantics is as in run_job (eager mode): the
+// range-check flags are read once at the end, a job with a set flag is re-run in
+// the careful order from its untouched host input.
+
+static int comp_rebalance(const qs_hip_job* job, int ci, int flags) {
+  const int luma = !ci || job->colorspace != 3;                                     // reference :2639
+  return !(flags & QS_NO_REBALANCE) && (luma || !(flags & QS_NO_REBALANCE_UV));       // :1567-1568
+}
+
+static bool job_needs_lowres(const qs_hip_job* job, int flags) {                     // reference :2447-2453
+  return (flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV)) && job->colorspace == 3 && job->ncomp >= 3 &&
+         job->hsamp[1] == 1 && job->vsamp[1] == 1 && job->hsamp[2] == 1 && job->vsamp[2] == 1;
+}
+
+static bool job_fusable(const qs_hip_job* job, int flags) {
+  static const bool off = getenv("QS_HIP_NO_FUSE") != nullptr;
+  if (off || (flags & QS_LOW_QUALITY) || job_needs_lowres(job, flags)) return false;
+  for (int ci = 0; ci < job->ncomp; ++ci) {
+    if (!job->has_quant[ci]) return false;
+    int acc = 0;
+    for (int i = 0; i < 64; ++i) acc |= job->quant[ci][i];
+    if (acc <= 1 || acc >= 0x800) return false;          // iterations skipped / stop: the general path knows how
+  }
+  return true;
+}
+
+// One device plane of a set: a whole component, or a band of block rows of a very large
+// one (rows [src_row0, src_row0 + hb) of the source, of which [keep0, keep1) are results:
+// the rest is halo, see split_rows).
+struct FPlane { int job, ci, wb, hb, cst; size_t coef_off, px_off, cbytes; int src_row0, keep0, keep1; };
+struct FGroup {
+  std::vector<FPlane> planes;
+  std::vector<int> jobs;                  // indices into the caller's job list
+  DevBuf coef, px, cst, status;
+  PinnedBuf stage;
+  std::vector<QsConsts> hc;               // host copies stay alive until the stream is drained
+  PinnedBuf hstatus;                      // range-check flags
+  Download down;                          // results on their way back
+  hipStream_t s = nullptr;
+  size_t blocks = 0, coef_bytes = 0;
+};
+struct DrainGuard {                       // error paths: nothing may be freed while the streams still run
+  Streams* st;
+  ~DrainGuard() { for (auto& x : st->s) (void)hipStreamSynchronize(x); }
+};
+
+// a group of >= 3 waves per SIMD runs at the streaming rate; smaller groups let the upload of one
+// overlap the kernels of the previous and the download of the one before (three streams)
+static const size_t kGroupBlocks = (size_t)200 << 10;
+// A plane above kSplitBlocks is cut into bands of about kBandBlocks that travel as separate
+// groups, so its upload, kernels and download overlap as they do for a batch of small jobs.
+// A block's result after n iterations depends only on blocks within n rows of it, so a band
+// carries n extra block rows on each cut side (recomputed, not copied back): bit-exact.
+// (QS_HIP_SPLIT_BLOCKS / QS_HIP_BAND_BLOCKS override the two sizes: the tests use them to run
+// the band logic on small images.)
+static size_t env_size(const char* name, size_t dflt) {
+  const char* v = getenv(name);
+  const long long n = v ? atoll(v) : 0;
+  return n > 0 ? (size_t)n : dflt;
+}
+static const size_t kSplitBlocks = env_size("QS_HIP_SPLIT_BLOCKS", (size_t)512 << 10),
+                    kBandBlocks = env_size("QS_HIP_BAND_BLOCKS", (size_t)256 << 10);
+
+static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int flags, int niter, int* results) {
+  StreamLease lease;
+  if (!lease.p) return qs_fail(QS_HIP_ENODEV, "could not create HIP streams: %s", hipGetErrorString(hipGetLastError()));
+  std::list<FGroup> groups;
+  DrainGuard drain{lease.p};
+  const double t_start = wall_ms();
+
+  // ---- partition into groups (a job never straddles two, unless it is cut into bands)
+  int maxj = 0;
+  for (int ji : which) maxj = std::max(maxj, ji);
+  std::vector<char> split(maxj + 1, 0), bad_job(maxj + 1, 0), scattered(maxj + 1, 0), defer(maxj + 1, 0);
+  for (int ji : which) {
+    const qs_hip_job* job = jobs[ji];
+    size_t jblocks = 0;
+    bool big = false;
+    for (int ci = 0; ci < job->ncomp; ++ci) {
+      const size_t nb = (size_t)job->wblk[ci] * job->hblk[ci];
+      jblocks += nb;
+      const int bands = (int)((nb + kBandBlocks - 1) / kBandBlocks);
+      if (nb > kSplitBlocks && (job->hblk[ci] + bands - 1) / bands >= 8 * niter) big = true;   // halo <= 25 %
+    }
+    if (big) {
+      split[ji] = 1;
+      for (int ci = 0; ci < job->ncomp; ++ci) {
+        const int wb = job->wblk[ci], hb = job->hblk[ci];
+        const int bands = std::max(1, (int)(((size_t)wb * hb + kBandBlocks - 1) / kBandBlocks));
+        const int rows = (hb + bands - 1) / bands;
+        for (int r0 = 0; r0 < hb; r0 += rows) {
+          const int r1 = std::min(hb, r0 + rows), d0 = std::max(0, r0 - niter), d1 = std::min(hb, r1 + niter);
+          groups.emplace_back();
+          FGroup& G = groups.back();
+          G.jobs.push_back(ji);
+          G.blocks = (size_t)wb * (d1 - d0);
+          G.planes.push_back({ji, ci, wb, d1 - d0, -1, 0, 0, (size_t)wb * (d1 - d0) * 128, d0, r0 - d0, r1 - d0});
+        }
+      }
+      groups.emplace_back();                                 // the next job starts a fresh group
+      continue;
+    }
+    if (groups.empty() || (int)groups.back().planes.size() + job->ncomp > QS_MAX_PLANES ||
+        (groups.back().blocks && groups.back().blocks + jblocks > kGroupBlocks))
+      groups.emplace_back();
+    FGroup& G = groups.back();
+    G.jobs.push_back(ji);
+    G.blocks += jblocks;
+    for (int ci = 0; ci < job->ncomp; ++ci)
+      G.planes.push_back({ji, ci, job->wblk[ci], job->hblk[ci], -1, 0, 0, (size_t)job->wblk[ci] * job->hblk[ci] * 128,
+                          0, 0, job->hblk[ci]});
+  }
+  groups.remove_if([](const FGroup& g) { return g.planes.empty(); });   // placeholders left by band jobs
+
+  // ---- enqueue every group: upload, niter x (pass A, pass B), status readback
+  const int diag = (flags & QS_DIAGONALS) != 0;
+  size_t gi = 0;
+  for (FGroup& G : groups) {
+    G.s = lease.p->s[gi++ % 3];
+    const int np = (int)G.planes.size();
+    size_t coef_bytes = 0, px_bytes = 0;
+    std::vector<const uint16_t*> qtabs;
+    for (FPlane& P : G.planes) {
+      P.coef_off = coef_bytes; coef_bytes += P.cbytes;
+      P.px_off = px_bytes; px_bytes += (qs_hip_plane_bytes(P.wb, P.hb) + 255) & ~(size_t)255;
+      const uint16_t* q = jobs[P.job]->quant[P.ci];
+      for (size_t k = 0; k < qtabs.size() && P.cst < 0; ++k)
+        if (!memcmp(qtabs[k], q, 64 * sizeof(uint16_t))) P.cst = (int)k;
+      if (P.cst < 0) { P.cst = (int)qtabs.size(); qtabs.push_back(q); }
+    }
+    HIP_TRY(G.coef.alloc(coef_bytes));
+    HIP_TRY(G.px.alloc(px_bytes));
+    HIP_TRY(G.cst.alloc(qtabs.size() * sizeof(QsConsts)));
+    HIP_TRY(G.status.alloc((size_t)np * sizeof(int32_t)));
+    G.hc.resize(qtabs.size());
+    for (size_t k = 0; k < qtabs.size(); ++k)
+      if (int r = qs_hip_consts_build(&G.hc[k], qtabs[k], flags)) return r;
+    HIP_TRY(hipMemcpyAsync(G.cst.p, G.hc.data(), qtabs.size() * sizeof(QsConsts), hipMemcpyHostToDevice, G.s));
+    std::vector<Piece> pieces;
+    for (const FPlane& P : G.planes)
+      pieces.push_back({jobs[P.job]->coef[P.ci] + (size_t)P.src_row0 * P.wb * 64, P.coef_off, P.cbytes});
+    G.coef_bytes = coef_bytes;
+    HIP_TRY(upload_pieces(G.coef.p, pieces, coef_bytes, G.s, G.stage));
+    HIP_TRY(hipMemsetAsync(G.status.p, 0, (size_t)np * sizeof(int32_t), G.s));
+
+    QsPlaneSet set;
+    memset(&set, 0, sizeof set);
+    set.n = np;
+    int w = 0;
+    for (int i = 0; i < np; ++i) {
+      const FPlane& P = G.planes[i];
+      set.wave0[i] = w;
+      w += (P.wb * P.hb + 63) / 64;
+      QsPlaneRef& R = set.ref[i];
+      R.cst = G.cst.as<QsConsts>() + P.cst;
+      R.coef = reinterpret_cast<int16_t*>(G.coef.as<char>() + P.coef_off);
+      R.plane = G.px.as<uint8_t>() + P.px_off;
+      R.status = G.status.as<int32_t>() + i;
+      R.wblk = P.wb; R.hblk = P.hb; R.pitch = qs_plane_pitch(P.wb);
+      R.rebalance = comp_rebalance(jobs[P.job], P.ci, flags);
+    }
+    for (int i = np; i < QS_MAX_PLANES + 2; ++i) set.wave0[i] = w;
+    for (int it = 0; it < niter; ++it) {
+      qs_launch_idct_set(set, it == 0, G.s);
+      qs_launch_smooth_set(set, diag, it == niter - 1, G.s);
+    }
+    HIP_TRY(hipGetLastError());
+    // pinned: a pageable destination would make this call wait for the whole stream
+    if (!G.hstatus.alloc((size_t)np * sizeof(int32_t))) return qs_fail(QS_HIP_ENOMEM, "out of pinned host memory");
+    HIP_TRY(hipMemcpyAsync(G.hstatus.p, G.status.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, G.s));
+    HIP_TRY(G.down.issue(G.coef.p, coef_bytes, G.s));       // to pinned memory, right behind the kernels
+  }
+  const double t_enq = wall_ms();
+
+  // ---- drain group by group; results go back only for jobs whose range check passed.
+  // A job cut into bands is scattered band by band before its later bands have been
+  // checked: should one of those trip the range check after all (crafted file), the rows
+  // already written are restored from the pinned upload staging, which still holds the
+  // original input.  Without that staging copy (pinned memory exhausted) the job's bands
+  // are held back until all of them have been checked.
+  auto result_piece = [&](const FPlane& P) {
+    const size_t row = (size_t)P.wb * 128;
+    return Piece{jobs[P.job]->coef[P.ci] + (size_t)(P.src_row0 + P.keep0) * P.wb * 64,
+                 P.coef_off + P.keep0 * row, (size_t)(P.keep1 - P.keep0) * row};
+  };
+  for (FGroup& G : groups)
+    if (!G.stage.p) for (int ji : G.jobs) if (split[ji]) defer[ji] = 1;
+  std::vector<FGroup*> held;
+  for (FGroup& G : groups) {
+    HIP_TRY(G.down.wait_first(G.s));
+    const int32_t* hst = static_cast<const int32_t*>(G.hstatus.p);
+    for (size_t i = 0; i < G.planes.size(); ++i) if (hst[i]) bad_job[G.planes[i].job] = 1;
+    bool hold = false;
+    for (int ji : G.jobs) hold |= (defer[ji] != 0);
+    if (hold) { held.push_back(&G); continue; }
+    std::vector<Piece> back;
+    for (const FPlane& P : G.planes)
+      if (!bad_job[P.job]) { back.push_back(result_piece(P)); scattered[P.job] = 1; }
+    HIP_TRY(G.down.finish(G.coef.p, back, G.s));
+  }
+  for (FGroup* G : held) {
+    std::vector<Piece> back;
+    for (const FPlane& P : G->planes) if (!bad_job[P.job]) back.push_back(result_piece(P));
+    HIP_TRY(G->down.finish(G->coef.p, back, G->s));
+  }
+  std::vector<int> rerun;
+  for (int ji : which) {
+    if (!bad_job[ji]) { results[ji] = 0; continue; }
+    rerun.push_back(ji);
+    if (!scattered[ji]) continue;                            // host input is still untouched
+    for (FGroup& G : groups)                                 // put the original rows back
+      for (const FPlane& P : G.planes)
+        if (P.job == ji && G.stage.p) {
+          const Piece pc = result_piece(P);
+          memcpy(pc.host, static_cast<const char*>(G.stage.p) + pc.off, pc.len);
+        }
+  }
+  if (trace_on())
+    fprintf(stderr, "qs_hip trace: fused  %zu job(s) in %zu group(s)  enqueue %.2f ms  drain+download %.2f ms  (%zu re-run)\n",
+            which.size(), groups.size(), t_enq - t_start, wall_ms() - t_enq, rerun.size());
+  for (int ji : which) {
+    if (bad_job[ji]) continue;
+    for (int ci = 0; ci < jobs[ji]->ncomp; ++ci)           // reference :2851-2859
+      for (int i = 0; i < 64; ++i) jobs[ji]->quant[ci][i] = 1;
+  }
+  const double t_clear = wall_ms();
+  groups.clear();                                            // give the arenas back before the re-runs allocate
+  if (trace_on()) fprintf(stderr, "qs_hip trace: fused  release %.2f ms\n", wall_ms() - t_clear);
+  for (int ji : rerun)
+    results[ji] = run_job(jobs[ji], flags, niter, 0, nullptr, nullptr, /*eager=*/false);
+  return QS_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" void qs_hip_release_cache(void) {
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  for (auto& c : g_cache) (void)hipFree(c.p);
+  g_cache.clear();
+  for (auto* sp : g_stream_pool) delete sp;
+  g_stream_pool.clear();
+  for (auto& c : PinnedBuf::pool()) (void)hipHostFree(c.p);
+  PinnedBuf::pool().clear();
+}
+
+// validation and the reference's early-outs; returns 1 when there is work to do,
+// 0 when the job is already finished (result 0), < 0 on a bad job
+static int prepare_job(qs_hip_job* job, int flags, int* niter) {
+  if (!job || job->ncomp < 1 || job->ncomp > QS_HIP_MAXC)
+    return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: bad job");
+  for (int ci = 0; ci < job->ncomp; ++ci)
+    if (!job->coef[ci] || job->wblk[ci] <= 0 || job->hblk[ci] <= 0)
+      return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: component %d has no data", ci);
+  job->up_wblk = job->up_hblk = 0; job->coef_up[0] = job->coef_up[1] = nullptr;
+  job->out_hsamp0 = job->hsamp[0]; job->out_vsamp0 = job->vsamp[0];
+  if (*niter < 0) *niter = 0;
+  if (*niter > 100) *niter = 100;                          // reference :2455-2456
+  if (*niter <= 0 && !((flags & QS_UPSAMPLE_UV) && job_needs_lowres(job, flags))) return 0;  // reference :2458
+  return 1;
+}
+
+extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int progprec,
+                                     qs_hip_progress_fn progress, void* userdata) {
+  const int todo = prepare_job(job, flags, &niter);
+  if (todo <= 0) return todo;
+  if (qs_hip_device_count() <= 0)
+    return qs_fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+
+  if (!progress && job_fusable(job, flags)) {
+    int result = QS_HIP_ENODEV;
+    qs_hip_job* one[1] = { job };
+    if (int r = run_fused(one, std::vector<int>{0}, flags, niter, &result)) return r;
+    return result;
+  }
+  int r = run_job(job, flags, niter, progprec, progress, userdata, /*eager=*/progress == nullptr);
+  if (r == JOB_RERUN_CAREFUL)
+    r = run_job(job, flags, niter, progprec, progress, userdata, /*eager=*/false);
+  return r;
+}
+
+extern "C" int qs_hip_do_quantsmooth_batch(qs_hip_job* const* jobs, int njobs, int flags, int niter, int* results) {
+  if (!jobs || !results || njobs < 0) return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth_batch: null argument");
+  std::vector<int> fused, single;
+  const int nit = niter < 0 ? 0 : niter > 100 ? 100 : niter;     // reference :2455-2456
+  for (int j = 0; j < njobs; ++j) {
+    int n1 = niter;
+    const int todo = prepare_job(jobs[j], flags, &n1);
+    results[j] = todo < 0 ? todo : 0;
+    if (todo <= 0) continue;
+    (job_fusable(jobs[j], flags) ? fused : single).push_back(j);
+  }
+  if (fused.empty() && single.empty()) return QS_HIP_OK;
+  if (qs_hip_device_count() <= 0)
+    return qs_fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+  if (!fused.empty()) {
+    for (int j : fused) results[j] = QS_HIP_ENODEV;
+    const double t0 = wall_ms();
+    const int r = run_fused(jobs, fused, flags, nit, results);
+    if (trace_on()) fprintf(stderr, "qs_hip trace: batch  run_fused total %.2f ms\n", wall_ms() - t0);
+    if (r) return r;
+  }
+  for (int j : single)                                       // coupled / special jobs: the general path, one by one
+    results[j] = qs_hip_do_quantsmooth(jobs[j], flags, niter, 0, nullptr, nullptr);
+  return QS_HIP_OK;
+}
+

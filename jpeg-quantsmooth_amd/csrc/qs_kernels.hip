@@ -372,7 +372,7 @@ __device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
 // Scaling by powers of two commutes with IEEE rounding as long as nothing
 // underflows; the smallest non-zero magnitudes are |x'| >= 2^-36 and
 // |y'| >= min|w| * 2^-24 with min|w| ~ 2^-29 (checked when the tables are
-// built, qs_host.cpp), so products stay above 2^-110 and sums of such terms are
+// built, qs_tables.cpp), so products stay above 2^-110 and sums of such terms are
 // exact multiples of 2^-149.  Every rounding therefore happens on the same
 // significand as in the reference's unscaled evaluation: bit-exact.
 #define QS_PIX_SCALE 0.000244140625f /* 2^-12 */
@@ -530,7 +530,7 @@ qs_dequant_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef, 
 }
 
 // --------------------------------------------------------------------------
-// launchers (C++ linkage, used by qs_host.cpp through qs_launch.h)
+// launchers (C++ linkage, used by qs_planes.cpp and qs_job.cpp through qs_launch.h)
 #include "qs_launch.h"
 
 void qs_launch_idct_plane(const QsConsts* cst, int16_t* coef, uint8_t* plane, int wblk, int hblk,
