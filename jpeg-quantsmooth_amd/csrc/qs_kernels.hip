@@ -430,6 +430,14 @@ __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >
 #define QS_WAVES_PER_WG 4
 #endif
 
+// tail-round wave priority (see qs_smooth_kernel.inc); workgroups the chip holds at
+// once = 256 CUs x 3 (the kernel's VGPR budget leaves room for 3 waves per SIMD and a
+// workgroup puts one wave on each of a CU's four SIMDs)
+#ifndef QS_TAIL_PRIO
+#define QS_TAIL_PRIO 1
+#endif
+#define QS_RESIDENT_WG (256 * 3 * 4 / QS_WAVES_PER_WG)
+
 #if QS_SKIP_ZERO_WEIGHTS
 #define QS_TERM_OPT(COND, A, B, W) { float d_, t_; \
         asm volatile( \
