@@ -21,7 +21,6 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 import jpegqs_pkg  # noqa: E402
 from helpers import inject_extreme_blocks  # noqa: E402
-from oracle.oracle import Oracle  # noqa: E402
 
 import hashlib  # noqa: E402
 import json  # noqa: E402
@@ -75,6 +74,7 @@ def kwargs(j):
 
 
 if mode == "gen":
+    from oracle.oracle import Oracle          # the replay side (`run`) never touches the oracle
     oracle = Oracle()
     ntrials = int(sys.argv[3]); seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     t0 = time.time()
