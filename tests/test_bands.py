@@ -52,7 +52,7 @@ def _worker(rank, world, port, flags, niter, tmp, overlapped=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,overlapped", [(2, False), (3, False), (2, True), (4, True)])
+@pytest.mark.parametrize("world,overlapped", [(2, False), (3, False), (8, False), (2, True), (4, True)])
 @pytest.mark.parametrize("flags", [0, 1])
 def test_bands_gloo_equal_unsharded(world, overlapped, flags, oracle, synth, tmp_path):
     """world_size > 1, CPU, gloo: bands + halo exchange reproduce the unsharded result
