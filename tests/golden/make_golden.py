@@ -102,6 +102,16 @@ def make_cli_golden():
             dst = out / f"{src}.q{q}.ref.jpg"
             subprocess.run([str(cli), "-q", str(q), "-n", "3", "-i", "0", "-t", "1",
                             str(out / f"{src}.jpg"), str(dst)], check=True)
+    # more container variety: 4 components (Adobe CMYK), progressive scans, 4:2:2, restart markers
+    cmyk = np.stack([synth.synth_pixels(96, 64, seed=7, variant=v % 3) for v in range(4)], axis=-1)
+    Image.fromarray(cmyk, "CMYK").save(out / "cmyk96x64.jpg", quality=55)
+    rgb2 = np.stack([synth.synth_pixels(120, 88, seed=9, variant=v) for v in range(3)], axis=-1)
+    Image.fromarray(rgb2, "RGB").save(out / "rgb120x88_prog.jpg", quality=45, subsampling=2, progressive=True)
+    Image.fromarray(rgb2, "RGB").save(out / "rgb120x88_422_rst.jpg", quality=70, subsampling=1, restart_marker_blocks=4)
+    for src, qs in (("cmyk96x64", (3, 4, 6)), ("rgb120x88_prog", (3, 6)), ("rgb120x88_422_rst", (2, 5, 6))):
+        for q in qs:
+            subprocess.run([str(cli), "-q", str(q), "-n", "3", "-i", "0", "-t", "1",
+                            str(out / f"{src}.jpg"), str(out / f"{src}.q{q}.ref.jpg")], check=True)
     print(sorted(p.name for p in out.iterdir()))
 
 

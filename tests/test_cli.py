@@ -71,6 +71,21 @@ def test_cli_matches_reference_cli_bytes(gpu, tmp_path, src, quality):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("src,quality", [("cmyk96x64", 3), ("cmyk96x64", 4), ("cmyk96x64", 6),
+                                         ("rgb120x88_prog", 3), ("rgb120x88_prog", 6),
+                                         ("rgb120x88_422_rst", 2), ("rgb120x88_422_rst", 5), ("rgb120x88_422_rst", 6)])
+def test_cli_container_variety_matches_reference_cli_bytes(gpu, tmp_path, src, quality):
+    """four components (Adobe CMYK: every component is "luma" for the recovery loop, reference
+    quantsmooth.h:2639), progressive scans in, 4:2:2 with restart markers"""
+    _need_cli()
+    out = tmp_path / "o.jpg"
+    r = subprocess.run([str(CLI), "-q", str(quality), "-n", "3", "-i", "0", str(GOLD / f"{src}.jpg"), str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == (GOLD / f"{src}.q{quality}.ref.jpg").read_bytes()
+
+
+@pytest.mark.gpu
 def test_cli_stdin_stdout_and_inplace(gpu, tmp_path):
     _need_cli()
     data = (GOLD / "gray64.jpg").read_bytes()
