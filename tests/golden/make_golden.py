@@ -83,6 +83,11 @@ if __name__ == "__main__":
     main()
 
 
+CLI_OPTION_CASES = [("f33", ["-f", "33", "-n", "2"]), ("f20_n1", ["--flags", "20", "--niter", "1"]),
+                    ("c0", ["-q", "3", "-n", "3", "-c", "0"]), ("c1", ["-q", "3", "-n", "3", "--copy", "1"]),
+                    ("q5_n0", ["-q", "5", "-n", "0"]), ("q6_n1_o", ["-q", "6", "-n", "1", "-o"])]
+
+
 def make_cli_golden():
     """JPEG files in -> reference CLI (scalar build) -> JPEG files out, committed
     so the end-to-end CLI test can run where /root/reference is absent."""
@@ -112,6 +117,10 @@ def make_cli_golden():
         for q in qs:
             subprocess.run([str(cli), "-q", str(q), "-n", "3", "-i", "0", "-t", "1",
                             str(out / f"{src}.jpg"), str(out / f"{src}.q{q}.ref.jpg")], check=True)
+    # option coverage: --flags override (NO_REBALANCE_UV + DIAGONALS), --copy 0/1, --optimize with progressive input
+    for tag, args in CLI_OPTION_CASES:
+        subprocess.run([str(cli), *args, "-i", "0", "-t", "1", str(out / "rgb141x93_420.jpg"),
+                        str(out / f"rgb141x93_420.{tag}.ref.jpg")], check=True)
     print(sorted(p.name for p in out.iterdir()))
 
 

@@ -86,6 +86,20 @@ def test_cli_container_variety_matches_reference_cli_bytes(gpu, tmp_path, src, q
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag,args", [("f33", ["-f", "33", "-n", "2"]), ("f20_n1", ["--flags", "20", "--niter", "1"]),
+                                      ("c0", ["-q", "3", "-n", "3", "-c", "0"]), ("c1", ["-q", "3", "-n", "3", "--copy", "1"]),
+                                      ("q5_n0", ["-q", "5", "-n", "0"]), ("q6_n1_o", ["-q", "6", "-n", "1", "-o"])])
+def test_cli_option_cases_match_reference_cli_bytes(gpu, tmp_path, tag, args):
+    """--flags override, --copy 0/1 (marker copying), niter 0, --optimize: same bytes as the reference CLI
+    (the cases are tests/golden/make_golden.py's CLI_OPTION_CASES)"""
+    _need_cli()
+    out = tmp_path / "o.jpg"
+    r = subprocess.run([str(CLI), *args, "-i", "0", str(GOLD / "rgb141x93_420.jpg"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == (GOLD / f"rgb141x93_420.{tag}.ref.jpg").read_bytes()
+
+
+@pytest.mark.gpu
 def test_cli_stdin_stdout_and_inplace(gpu, tmp_path):
     _need_cli()
     data = (GOLD / "gray64.jpg").read_bytes()
