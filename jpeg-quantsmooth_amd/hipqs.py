@@ -130,7 +130,9 @@ def _share_hip_runtime_with_torch() -> None:
 
 
 def lib_path() -> Path:
-    return PKG_DIR / "libjpegqs_hip.so"
+    """the in-tree library; QS_HIP_LIB points measurement runs at an A/B build (tools/build_variants.sh)"""
+    import os
+    return Path(os.environ["QS_HIP_LIB"]) if os.environ.get("QS_HIP_LIB") else PKG_DIR / "libjpegqs_hip.so"
 
 
 def load_library(path: Path | None = None) -> C.CDLL:

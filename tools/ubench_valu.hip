@@ -823,7 +823,8 @@ __global__ void k_dot2c(int* out, int a) {
 
 template <class K, class T>
 static void run(const char* name, K kern, T* out, T arg, double lane_ops_per_thread_iter, int pk) {
-  for (int wps = 1; wps <= 8; wps *= 2) {
+  static const int kWps[] = {1, 2, 3, 4, 8};
+  for (int wps : kWps) {
     dim3 grid(256 * wps), block(256);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(kern, grid, block, 0, 0, out, arg);
@@ -838,7 +839,8 @@ static void run(const char* name, K kern, T* out, T arg, double lane_ops_per_thr
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool term_only = argc > 1 && argv[1][0] == 't';
   float* out; hipMalloc(&out, sizeof(float) * 256 * 8 * 256);
   float* tab; hipMalloc(&tab, 1 << 20); hipMemset(tab, 0x3c, 1 << 20);
   for (int wps = 1; wps <= 4; wps *= 2) {
@@ -864,6 +866,20 @@ int main() {
     int trips = ITER * 4 / 112;
     double instr = (double)grid.x * 256 * trips * 112 * 9;
     printf("term9 16 sgprs no load waves/SIMD=%d  %.3f ms  %.2f T lane-instr/s\n", wps, ms, instr / ms * 1e-9);
+  }
+  if (term_only) {
+    run("term9 x4", k_term9, out, 0.5f, 36, 1);
+    run("term9 serial", k_term9_serial, out, 0.5f, 36, 1);
+    run("term9 x2", k_term9_x2, out, 0.5f, 36, 1);
+    run("mul+add", k_mul_add, out, 1.0001f, 16, 1);
+    run("dep_add", k_dep_add, out, 1.0001f, 16, 1);
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'f') {        // instruction-footprint probe only
+    run("term9 body64", k_term9_big<64>, out, 0.5f, 36, 1);
+    run("term9 body256", k_term9_big<256>, out, 0.5f, 36, 1);
+    run("term9 body1024", k_term9_big<1024>, out, 0.5f, 36, 1);
+    return 0;
   }
   run("mul+add", k_mul_add, out, 1.0001f, 16, 1);
   run("pk_mul+pk_add", k_pk_mul_add, out, 1.0001f, 16, 2);
