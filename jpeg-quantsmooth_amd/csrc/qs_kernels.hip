@@ -50,6 +50,12 @@ __device__ __forceinline__ uint32_t mulc(uint32_t a, int c) {
   return (uint32_t)__mul24((int)a, c);
 }
 
+__device__ __forceinline__ uint32_t lshl13_add(uint32_t x, uint32_t b) {
+  uint32_t r;
+  asm("v_lshl_add_u32 %0, %1, 13, %2" : "=v"(r) : "v"(x), "v"(b));
+  return r;
+}
+
 // 1-D LL&M inverse DCT butterfly, 13-bit constants, wrapping int32 arithmetic.
 // Behaviour of reference idct.h:57-89.
 // `bias` (the rounding constant of the descale that follows, plus the level shift
@@ -62,14 +68,20 @@ __device__ __forceinline__ void idct8(uint32_t (&v)[8], uint32_t bias) {
   uint32_t z1, z2, z3, z4, z5, t0, t1, t2, t3, e0, e1, e2, e3;
   z2 = v[2]; z3 = v[6];
   z1 = mulc(z2 + z3, 4433);
+  // a product with two consumers is made opaque: hipcc otherwise recomputes it inside two
+  // v_mad_i32_i24 (it prices a multiply-add like an add; on gfx950 it costs about four)
+  asm volatile("" : "+v"(z1));
   t2 = z1 - mulc(z3, 15137);
   t3 = z1 + mulc(z2, 6270);
-  t0 = ((v[0] + v[4]) << 13) + bias;
-  t1 = ((v[0] - v[4]) << 13) + bias;
+  // (x << 13) + bias as ONE v_lshl_add_u32: left to itself hipcc emits v_mad_i32_i24 x, 8192, bias,
+  // and integer multiplies cost about four adds on gfx950 (measured by ablation)
+  t0 = lshl13_add(v[0] + v[4], bias);
+  t1 = lshl13_add(v[0] - v[4], bias);
   e0 = t0 + t3; e3 = t0 - t3; e1 = t1 + t2; e2 = t1 - t2;
   t0 = v[7]; t1 = v[5]; t2 = v[3]; t3 = v[1];
   z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; z4 = t1 + t3;
   z5 = mulc(z3 + z4, 9633);
+  asm volatile("" : "+v"(z5));
   t0 = mulc(t0, 2446);  t1 = mulc(t1, 16819);
   t2 = mulc(t2, 25172); t3 = mulc(t3, 12299);
   z1 = mulc(z1, 7373);  z2 = mulc(z2, 20995);
