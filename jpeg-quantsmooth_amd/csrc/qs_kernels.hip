@@ -442,6 +442,11 @@ __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >
 #define QS_WAVES_PER_WG 4
 #endif
 
+// QS_FUSE_REBALANCE_SUMS: collect the rebalance step's two sums while the coefficients are
+// updated (see qs_smooth_kernel.inc); 0 = separate pass over the block afterwards
+#ifndef QS_FUSE_REBALANCE_SUMS
+#define QS_FUSE_REBALANCE_SUMS 1
+#endif
 // tail-round wave priority (see qs_smooth_kernel.inc); workgroups the chip holds at
 // once = 256 CUs x 3 (the kernel's VGPR budget leaves room for 3 waves per SIMD and a
 // workgroup puts one wave on each of a CU's four SIMDs)
