@@ -19,9 +19,9 @@ __device__ __forceinline__ float round_half_away(float x) {
 // nearest multiple of the quantiser (ties away from zero) via the reference's
 // reciprocal tables, and the interval that quantises to it.
 // reference quantsmooth.h:332-336, 1552-1557.
-__device__ __forceinline__ void interval(int c, int div, int x1, int x2, int& orig, int& lo, int& hi) {
+__device__ __forceinline__ void interval(int c, int div, int x1, int sh, int& orig, int& lo, int& hi) {
   int a = ((x1 * c) >> 16) + c;
-  a = (-a * x2 + 0x4000) >> 15;
+  a = (int)(((uint32_t)a << sh) + 0x4000u) >> 15;   // == (-a * x2 + 0x4000) >> 15 with x2 = -(1 << sh), see QsConsts::x2
   a *= div;
   const int d0 = (div - 1) >> 1, d1 = div >> 1;
   orig = a;

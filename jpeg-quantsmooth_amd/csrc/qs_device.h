@@ -31,7 +31,7 @@ struct QsConsts {
   int32_t q[64];       // effective quantiser (0 -> 1), reference :2506-2511
   int32_t qraw[64];    // quantiser as stored in the file (natural index!)
   int32_t x1[64];      // reciprocal (as signed 16-bit), reference :2514-2539
-  int32_t x2[64];      // shift term (as signed 16-bit)
+  int32_t x2[64];      // 15 - floor(log2 q): the reference's x2 = -0x8000 >> n enters only as -a * x2 = a << (15 - n)
   float   range[64];   // (float)(2 * q) * 2^-12 (the kernel works on pixels * 2^-12)
   // natural-index copies for the rebalance pass (walks k = 1..63 natural)
   int32_t qn[64], x1n[64], x2n[64];

@@ -169,8 +169,11 @@ extern "C" int qs_hip_consts_build(void* host_out, const uint16_t quant[64], int
     while (t > 1) { t >>= 1; ++n; }
     unsigned x1 = ((0x10000u << n) + q - 1) / q;
     if (n) x1 |= x1 >> 16;
-    int x2 = -0x8000 >> n;
-    qn[i] = (int)q; x1n[i] = (int16_t)(uint16_t)x1; x2n[i] = (int16_t)(uint16_t)x2;
+    // the reference's second table entry is x2 = -0x8000 >> n, used as (-a * x2 + 0x4000) >> 15:
+    // -a * x2 == a << (15 - n), so the device table carries the shift (an integer multiply costs
+    // about four adds on gfx950, a shift one)
+    const int sh = 15 - (int)n;
+    qn[i] = (int)q; x1n[i] = (int16_t)(uint16_t)x1; x2n[i] = sh;
     c->qraw[i] = quant[i];
     c->qn[i] = qn[i]; c->x1n[i] = x1n[i]; c->x2n[i] = x2n[i];
   }

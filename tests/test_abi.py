@@ -56,7 +56,7 @@ def test_consts_tables_bit_exact(hip, oracle, synth):
             div = int(q[k])
             for c in (-3000, -div, -1, 0, 1, div // 2, div, 5 * div + 1, 3071):
                 a = ((int(x1[k]) * c) >> 16) + c
-                a = ((-a * int(x2[k]) + 0x4000) >> 15) * div
+                a = (((a << int(x2[k])) + 0x4000) >> 15) * div      # x2[k] holds the shift: -a * -(1 << sh)
                 assert a == oracle.interval(c, div)[0]
 
 
