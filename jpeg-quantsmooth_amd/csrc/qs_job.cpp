@@ -523,8 +523,8 @@ static int prepare_job(qs_hip_job* job, int flags, int* niter) {
   return 1;
 }
 
-extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int progprec,
-                                     qs_hip_progress_fn progress, void* userdata) {
+static int do_quantsmooth_impl(qs_hip_job* job, int flags, int niter, int progprec,
+                               qs_hip_progress_fn progress, void* userdata) {
   const int todo = prepare_job(job, flags, &niter);
   if (todo <= 0) return todo;
   if (qs_hip_device_count() <= 0)
@@ -542,7 +542,7 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
   return r;
 }
 
-extern "C" int qs_hip_do_quantsmooth_batch(qs_hip_job* const* jobs, int njobs, int flags, int niter, int* results) {
+static int do_quantsmooth_batch_impl(qs_hip_job* const* jobs, int njobs, int flags, int niter, int* results) {
   if (!jobs || !results || njobs < 0) return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth_batch: null argument");
   std::vector<int> fused, single;
   const int nit = niter < 0 ? 0 : niter > 100 ? 100 : niter;     // reference :2455-2456
@@ -564,7 +564,28 @@ extern "C" int qs_hip_do_quantsmooth_batch(qs_hip_job* const* jobs, int njobs, i
     if (r) return r;
   }
   for (int j : single)                                       // coupled / special jobs: the general path, one by one
-    results[j] = qs_hip_do_quantsmooth(jobs[j], flags, niter, 0, nullptr, nullptr);
+    results[j] = do_quantsmooth_impl(jobs[j], flags, niter, 0, nullptr, nullptr);
   return QS_HIP_OK;
 }
 
+// The C ABI never lets a C++ exception (std::bad_alloc from the host-side containers) escape.
+extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int progprec,
+                                     qs_hip_progress_fn progress, void* userdata) {
+  try {
+    return do_quantsmooth_impl(job, flags, niter, progprec, progress, userdata);
+  } catch (const std::bad_alloc&) {
+    return qs_fail(QS_HIP_ENOMEM, "out of host memory");
+  } catch (...) {
+    return qs_fail(QS_HIP_ENODEV, "unexpected internal error");
+  }
+}
+
+extern "C" int qs_hip_do_quantsmooth_batch(qs_hip_job* const* jobs, int njobs, int flags, int niter, int* results) {
+  try {
+    return do_quantsmooth_batch_impl(jobs, njobs, flags, niter, results);
+  } catch (const std::bad_alloc&) {
+    return qs_fail(QS_HIP_ENOMEM, "out of host memory");
+  } catch (...) {
+    return qs_fail(QS_HIP_ENODEV, "unexpected internal error");
+  }
+}
