@@ -81,8 +81,10 @@ int qs_hip_do_quantsmooth(qs_hip_job *job, int flags, int niter, int progprec,
  * reference API: an addition for callers that serve many images. */
 int qs_hip_do_quantsmooth_batch(qs_hip_job *const *jobs, int njobs, int flags, int niter, int *results);
 void qs_hip_free(void *p);
-/* the job layer keeps freed device buffers in a process-wide cache (up to 6 GiB);
- * this returns them to the driver */
+/* the job layer keeps freed device buffers (up to 6 GiB), pinned staging buffers (up to
+ * 2 GiB) and HIP streams in process-wide caches; this returns them to the driver.  (It also
+ * starts eight helper threads on first use, for the host side of large transfers; they
+ * sleep between jobs and live until the process ends.) */
 void qs_hip_release_cache(void);
 
 /* ---- plane layer (device pointers, async on `stream`) --------------------- */
