@@ -2,26 +2,35 @@
 """bench.py -- headline benchmark of the MI355X jpeg-quantsmooth hot path.
 
 Metric (BASELINE.json): 8x8 blocks/s at q=3 niter=3 on a synthetic 8192x8192 luma
-plane, inputs resident in HBM.  A "step" is one complete do_quantsmooth pass over
-one plane: niter x {IDCT-to-plane kernel, [halo exchange], recovery kernel}, final
-clamp fused into the last recovery launch.
+plane, inputs resident in HBM.  A "step" is one pass of the hot path over one BATCH of
+synthetic input: `--batch` (default 12) independent 8192x8192 planes, each taken through
+a complete do_quantsmooth -- niter x {IDCT-to-plane kernel, [halo exchange], recovery
+kernel}, final clamp fused into the last recovery launch.  (The batch only makes a step
+long enough that the driver's 20 timed steps cover about a second, i.e. the power-capped
+steady state; `value` counts blocks, so it does not depend on the batch size.)
 
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: the plane is split into N contiguous block-row bands (strong scaling, total
-work fixed, as BASELINE.json's north_star asks); after each IDCT pass a band swaps
-one pixel row with each neighbour over RCCL (torch.distributed send/recv), which is
-the only data-path communication the algorithm has.
+N > 1: every plane is split into N contiguous block-row bands (strong scaling, total
+work fixed, as BASELINE.json's north_star asks); after each IDCT pass a band swaps one
+pixel row with each neighbour over RCCL (torch.distributed send/recv), which is the only
+data-path communication the algorithm has.
+
+Workloads (BASELINE.json configs): default = 8192^2 luma, --quality 3 (the metric) or 4
+(configs[2]); --size 16384 (configs[3]); --quality 5/6 = 8192^2 4:2:0 YCbCr with
+JOINT_YUV (+ UPSAMPLE_UV), niter 5 (configs[4], cross-component stages, colour bands).
 
 One JSON line is printed by rank 0.  `roofline` is for the dominant kernel
 (qs_smooth_plane_kernel): achieved = algorithmic bytes (256 B per block per launch:
 read + write of 64 int16) / mean launch time measured with HIP events on the launch
 stream.  The kernel is FP32-VALU-bound, so `roofline_valu` gives the fraction of the
 non-FMA FP32 vector peak, which is the roofline that actually binds.
-`cpu_baseline` times the reference (oracle/_ref, AVX-512/AVX2 + OpenMP) -- or the
-oracle port when the reference build is absent -- on a bounded sample of the same
-workload on this box's host cores.
+`verify_ok`: the last timed step's result is compared with the CPU oracle on 16 block
+rows at the top, in the middle and at the bottom of the plane (N > 1: also on the rows
+either side of every band edge).  `cpu_baseline` times the compiled reference
+(oracle/_ref, AVX-512 and AVX2 builds, OpenMP) over a sweep of thread counts on a bounded
+sample of the same workload on this box's host cores.
 """
 from __future__ import annotations
 
@@ -42,16 +51,19 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 78.6        # 157.3 TF packed-FMA spec / 2: separate mul/add, no FMA allowed
 FLOP_PER_BLOCK_ITER = {0: 75e3, 1: 130e3}   # q3 / q4 (DIAGONALS)
 ALGO_BYTES_PER_BLOCK_ITER = 256
+RESIDENT_BUDGET = 64 << 30     # HBM the resident input planes of all steps may take
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", type=int, default=8192, help="luma plane is size x size pixels")
-    ap.add_argument("--quality", type=int, default=3, choices=(3, 4), help="jpegqs --quality (3 or 4)")
-    ap.add_argument("--niter", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=8192, help="the image is size x size pixels")
+    ap.add_argument("--quality", type=int, default=3, choices=(3, 4, 5, 6),
+                    help="jpegqs --quality: 3/4 = luma plane (the metric), 5/6 = 4:2:0 YCbCr with the cross-component stages")
+    ap.add_argument("--niter", type=int, default=None, help="default 3 (quality 3/4), 5 (quality 5/6: BASELINE configs[4])")
+    ap.add_argument("--batch", type=int, default=0, help="planes per step (0 = 12, fewer if the resident inputs would exceed 64 GiB)")
     ap.add_argument("--jpeg-quality", type=int, default=50, help="JPEG quality of the synthetic input")
     ap.add_argument("--weak", action="store_true", help="give every rank a full size x size plane")
     ap.add_argument("--overlap", action="store_true",
@@ -59,73 +71,131 @@ def parse_args():
                          "(measured slower on MI355X than the default in-order schedule, see DESIGN.md section 8)")
     ap.add_argument("--no-overlap", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="CPU baseline sample is NxN pixels")
-    ap.add_argument("--verify", action="store_true", help="check rows against the oracle after the run (N > 1: rows around every band edge)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sweep")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step")
+    ap.add_argument("--verify", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="torch.distributed backend (gloo: functional test of the sharded path)")
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (functional test of the sharded path on a 1-GPU box, with --backend gloo)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.niter is None:
+        a.niter = 5 if a.quality >= 5 else 3
+    return a
+
+
+def _synth_plane_gpu(torch, pkg, w, h, quant, dev, variant=0, seed=1234, squeeze=False):
+    """int16 [h/8, w/8, 64] quantised coefficients of the synthetic plane (formula of synth.py /
+    SURVEY.md 8d), float32 DCT via two small matmuls on the GPU"""
+    synth = pkg.synth
+    g = torch.Generator(device=dev); g.manual_seed(seed + 7919 * variant)
+    x = torch.arange(w, device=dev, dtype=torch.float32)[None, :]
+    y = torch.arange(h, device=dev, dtype=torch.float32)[:, None]
+    px, py = 17.0 + 5 * variant, 23.0 + 3 * variant
+    img = 128.0 + 60.0 * torch.sin(x / px) + 50.0 * torch.cos(y / py)
+    checker = ((torch.arange(w, device=dev) // (37 + 4 * variant))[None, :] + (torch.arange(h, device=dev) // (29 + 2 * variant))[:, None]) & 1
+    img = img + 40.0 * (checker.float() - 0.5)
+    img = img + torch.randn(h, w, device=dev, generator=g) * 6.0
+    y0, x0 = h // 5, w // 3
+    img[y0:y0 + h // 7, x0:x0 + w // 4] *= 0.45
+    img = img.round().clamp(0, 255)
+    if squeeze:   # chroma is smoother and nearer mid-grey in natural images (synth.synth_ycc)
+        img = (128 + torch.div(img - 128, 3, rounding_mode="floor")).clamp(0, 255)
+    img = img - 128.0
+    d = torch.from_numpy(synth._dct_matrix().astype(np.float32)).to(dev)
+    blk = img.reshape(h // 8, 8, w // 8, 8).permute(0, 2, 1, 3)
+    c = d @ blk @ d.T
+    q = torch.from_numpy(quant.astype(np.float32)).to(dev).reshape(8, 8)
+    return torch.round(c / q).to(torch.int16).reshape(h // 8, w // 8, 64).contiguous()
 
 
 def synth_input_gpu(torch, pkg, size, jpeg_quality, dev):
-    """Quantised coefficient plane built on the GPU (same formula as synth.py,
-    float32 DCT via two small matmuls): int16 [hblk, wblk, 64] + quant table."""
-    synth = pkg.synth
-    quant = synth.quality_table(synth.STD_LUMA, jpeg_quality)
-    g = torch.Generator(device=dev); g.manual_seed(1234)
-    x = torch.arange(size, device=dev, dtype=torch.float32)[None, :]
-    y = torch.arange(size, device=dev, dtype=torch.float32)[:, None]
-    img = 128.0 + 60.0 * torch.sin(x / 17.0) + 50.0 * torch.cos(y / 23.0)
-    checker = ((torch.arange(size, device=dev) // 37)[None, :] + (torch.arange(size, device=dev) // 29)[:, None]) & 1
-    img = img + 40.0 * (checker.float() - 0.5)
-    img = img + torch.randn(size, size, device=dev, generator=g) * 6.0
-    y0, x0 = size // 5, size // 3
-    img[y0:y0 + size // 7, x0:x0 + size // 4] *= 0.45
-    img = img.round().clamp(0, 255) - 128.0
-    d = torch.from_numpy(synth._dct_matrix().astype(np.float32)).to(dev)
-    blk = img.reshape(size // 8, 8, size // 8, 8).permute(0, 2, 1, 3)
-    c = d @ blk @ d.T
-    q = torch.from_numpy(quant.astype(np.float32)).to(dev).reshape(8, 8)
-    c = torch.round(c / q).to(torch.int16).reshape(size // 8, size // 8, 64).contiguous()
-    return c, quant
+    """luma workload: (coef int16 [hblk, wblk, 64] on the device, quant uint16[64])"""
+    quant = pkg.synth.quality_table(pkg.synth.STD_LUMA, jpeg_quality)
+    return _synth_plane_gpu(torch, pkg, size, size, quant, dev), quant
 
 
-def cpu_baseline(pkg, args, coef_full, quant, flags):
-    """Time the reference (oracle/_ref, best ISA this host runs, OpenMP on all
-    cores) -- or the oracle port if the reference build is absent -- on a
-    bounded sample: square crops of the workload, doubling until one run takes
-    >= 2 s or the whole plane is used; ~10-30 s of CPU work in total."""
-    from oracle import oracle as om
-    cores = os.cpu_count() or 1
-    variant = om.best_ref_variant()
-    if variant:
-        impl, kind, name = om.Reference(variant), "reference", f"reference {variant}+openmp"
-    else:
-        impl, kind, name = om.Oracle(), "port", "oracle port (scalar C + openmp)"
-    full = coef_full.shape[0]
-    n = min(max(args.cpu_sample // 8, 8), full)
-    best = None
-    t_all = time.time()
-    while True:
-        crop = np.ascontiguousarray(coef_full[:n, :n])
-        runs = []
-        for rep in range(3):
-            t0 = time.time()
-            impl.do_quantsmooth([crop], [quant], flags, args.niter, threads=0)
-            runs.append(time.time() - t0)
-            if time.time() - t_all > 25:
-                break
-        rate = n * n / min(runs)
-        if best is None or rate > best[0]:
-            best = (rate, n, min(runs), len(runs))
-        if min(runs) >= 2.0 or n >= full or time.time() - t_all > 15:
+def synth_colour_gpu(torch, pkg, size, jpeg_quality, dev):
+    """4:2:0 YCbCr workload: ([Y, Cb, Cr] coefficient tensors, [qY, qC, qC])"""
+    qy = pkg.synth.quality_table(pkg.synth.STD_LUMA, jpeg_quality)
+    qc = pkg.synth.quality_table(pkg.synth.STD_CHROMA, jpeg_quality)
+    y = _synth_plane_gpu(torch, pkg, size, size, qy, dev)
+    cb = _synth_plane_gpu(torch, pkg, size // 2, size // 2, qc, dev, variant=1, squeeze=True)
+    cr = _synth_plane_gpu(torch, pkg, size // 2, size // 2, qc, dev, variant=2, squeeze=True)
+    return [y, cb, cr], [qy, qc, qc.copy()]
+
+
+# ---------------------------------------------------------------------------
+# CPU baseline: the compiled reference on this box's host cores
+
+def _host_info():
+    info = {"os_cpu_count": os.cpu_count()}
+    try:
+        info["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        info["affinity_cpus"] = os.cpu_count()
+    for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            info["cgroup_cpu_max"] = Path(p).read_text().strip()
             break
-        n = min(n * 2, full)
-    rate, n, secs, reps = best
-    return {"value": rate, "unit": "blocks/s", "cores": cores, "kind": kind,
-            "sample": f"{n * 8}x{n * 8} px crop of the workload ({n * n} blocks), q={args.quality} "
-                      f"niter={args.niter}, {name}, threads={cores}, best of {reps}",
-            "seconds": secs}
+        except OSError:
+            pass
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                info["cpu_model"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return info
 
+
+def cpu_baseline(args, run_sample, total_units, unit_name, describe):
+    """Sweep thread counts for the AVX-512 and AVX2 builds of the UNMODIFIED reference
+    (oracle/_ref, OpenMP); the scalar oracle port only when no reference build travels with
+    the tree.  run_sample(impl, threads, frac) runs `frac` of the workload and returns the
+    number of blocks it processed.  About args.cpu_seconds of CPU work in total."""
+    from oracle import oracle as om
+    host = _host_info()
+    usable = max(1, int(host.get("affinity_cpus") or 1))
+    cg = str(host.get("cgroup_cpu_max", "max")).split()
+    if len(cg) == 2 and cg[0].isdigit() and int(cg[1]) > 0:       # cgroup v2 "quota period"
+        usable = max(1, min(usable, int(cg[0]) // int(cg[1])))
+    variants = [v for v in ("avx512", "avx2") if om.have_ref(v) and
+                all(om.cpu_has(f) for f in ({"avx512": ("avx512f", "avx512bw", "avx512dq", "fma"), "avx2": ("avx2", "fma")}[v]))]
+    impls = [(f"reference {v}+openmp", "reference", om.Reference(v)) for v in variants]
+    if not impls:
+        impls = [("oracle port (scalar C + openmp)", "port", om.Oracle())]
+    threads = sorted({t for t in (1, 8, 32, 64, 128, usable) if t <= usable})
+    budget = args.cpu_seconds / max(1, len(impls) * len(threads))
+    sweep, best, one_thread = {}, None, None
+    for name, kind, impl in impls:
+        sweep[name] = {}
+        rate_guess = 0.08e6                                        # blocks/s of one thread (AVX2/AVX-512 class)
+        for t in threads:
+            # a sample sized for about a third of this point's budget, then best of two runs
+            frac = min(1.0, max(1.0 / 512, rate_guess * t ** 0.85 * budget / 3 / total_units))
+            runs = []
+            t_point = time.time()
+            while len(runs) < 2 or (time.time() - t_point < budget * 0.5 and len(runs) < 4):
+                t0 = time.time()
+                n = run_sample(impl, t, frac)
+                runs.append(n / (time.time() - t0))
+            rate = max(runs)
+            sweep[name][str(t)] = round(rate)
+            if t == 1:
+                rate_guess = rate
+                if one_thread is None or rate > one_thread[0]:
+                    one_thread = (rate, name)
+            if best is None or rate > best[0]:
+                best = (rate, name, kind, t, frac)
+    rate, name, kind, t, frac = best
+    return {"value": rate, "unit": f"{unit_name}/s", "cores": t, "kind": kind,
+            "sample": f"{describe(frac)}, q={args.quality} niter={args.niter}, {name}, {t} OpenMP threads "
+                      f"(best point of the sweep; samples sized for ~{args.cpu_seconds:.0f} s of CPU work in total)",
+            "one_thread": {"value": one_thread[0], "impl": one_thread[1]} if one_thread else None,
+            "sweep_blocks_per_s": sweep, "host": host, "usable_cpus": usable}
+
+
+# ---------------------------------------------------------------------------
 
 def main():
     args = parse_args()
@@ -164,28 +234,117 @@ def main():
 
     pkg = jpegqs_pkg.load()
     hip = pkg.HipQS()          # raises if the HIP library is missing: no fallback
-    flags = pkg.flags_for_quality(args.quality)
-    size = args.size
-    hblk_total, wblk = size // 8, size // 8
-
-    # ---- band owned by this rank (jpeg-quantsmooth_amd/bands.py)
     from jpeg_quantsmooth_amd import bands
-    if args.weak or world == 1:
-        topo = bands.BandTopology(0, 1, 0, hblk_total)       # a whole plane per rank
-    else:
+    flags = pkg.flags_for_quality(args.quality)
+    colour = args.quality >= 5
+    size = args.size
+    sharded = world > 1 and not args.weak
+    verify = not args.no_verify
+    nsteps = args.steps + args.warmup
+    ctx = dict(args=args, torch=torch, dist=dist, pkg=pkg, hip=hip, bands=bands, flags=flags, size=size, world=world,
+               rank=rank, dev=dev, sharded=sharded, verify=verify, nsteps=nsteps)
+    run = run_colour if colour else run_luma
+    res = run(ctx)
+
+    if rank == 0:
+        value = res["total_blocks"] * args.steps / res["elapsed"]
+        kern_ms = res["kern_ms"]
+        if kern_ms is None:   # sharded run: no per-kernel events; derive from the step time (comm included)
+            kern_ms = res["elapsed"] / args.steps / res["batch"] / args.niter * 1e3
+        kblocks = res["kernel_blocks"]
+        achieved_gbs = kblocks * ALGO_BYTES_PER_BLOCK_ITER / (kern_ms * 1e-3) / 1e9
+        achieved_tf = kblocks * FLOP_PER_BLOCK_ITER[flags & 1] / (kern_ms * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        pmc = ROOT / "profiles" / "pmc_traffic.json"
+        if pmc.exists() and not colour and world == 1:
+            try:
+                j = json.loads(pmc.read_text())
+                traffic = j.get(f"q{args.quality}_{size}")
+                traffic_src = j.get("_source")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "8x8 blocks/s at q=%d niter=%d" % (args.quality, args.niter),
+            "value": value, "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["elapsed"] / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "mpixels_per_s": value * 64 / 1e6,
+            "timed_region_s": res["elapsed"],
+            "config": {"workload": res["workload"] +
+                       f", jpegqs --quality {args.quality} (flags={flags}) --niter {args.niter}; input = quantised float32-DCT "
+                       f"coefficients of the synthetic image of SURVEY.md 8d at JPEG quality {args.jpeg_quality} (built on the GPU; not "
+                       f"a libjpeg-encoded file, the CPU baseline consumes the same arrays)",
+                       "planes_per_step": res["batch"],
+                       "sharding": "none" if world == 1 else f"{world} block-row bands, 1-pixel-row halo over "
+                                                               f"{'RCCL' if args.backend == 'nccl' else 'gloo (host-staged)'} per iteration, "
+                                                               + ("exchange overlapped with the interior rows" if args.overlap
+                                                                  else "exchange between pass A and pass B in stream order"),
+                       "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
+                       "blocks_per_gpu": res["blocks_per_gpu"], **({"comm_note": comm_note} if comm_note else {})},
+            "roofline": {"bound": "hbm", "kernel": res["kernel"], "achieved": achieved_gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
+                         "kernel_launches_timed": res["kernel_launches"],
+                         "algorithmic_bytes_per_launch": kblocks * ALGO_BYTES_PER_BLOCK_ITER,
+                         "note": "kernel is FP32-VALU-bound (~290 flop/B); see roofline_valu"},
+            "roofline_valu": {"bound": "fp32-valu (separate mul/add, FMA forbidden by bit-exactness)",
+                              "achieved": achieved_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": achieved_tf / VALU_PEAK_TFLOPS,
+                              "flop_per_block_iter": FLOP_PER_BLOCK_ITER[flags & 1]},
+        }
+        for k in ("verify_ok", "verify_rows", "verify_detail", "verify_band_edges_ok"):
+            if res.get(k) is not None:
+                out[k] = res[k]
+        if res.get("cpu_baseline"):
+            out["cpu_baseline"] = res["cpu_baseline"]
+            out["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _fence(torch, dist, world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def _max_over_ranks(torch, dist, world, elapsed, dev, backend):
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def _batch_size(args, nsteps, bytes_per_plane):
+    want = args.batch if args.batch > 0 else 12
+    return max(1, min(want, RESIDENT_BUDGET // max(1, nsteps * bytes_per_plane)))
+
+
+# ---------------------------------------------------------------------------
+# luma plane (BASELINE configs[1..3]: the metric)
+
+def run_luma(c):
+    args, torch, dist, pkg, hip, bands = c["args"], c["torch"], c["dist"], c["pkg"], c["hip"], c["bands"]
+    flags, size, world, rank, dev = c["flags"], c["size"], c["world"], c["rank"], c["dev"]
+    hblk_total, wblk = size // 8, size // 8
+    if c["sharded"]:
         r0, r1 = bands.band_rows(hblk_total, world, rank)
         topo = bands.BandTopology(rank, world, r0, r1)
+    else:
+        topo = bands.BandTopology(0, 1, 0, hblk_total)       # a whole plane per rank
     r0, r1, hblk = topo.r0, topo.r1, topo.hblk
-    total_blocks = (hblk_total * wblk) * (world if args.weak else 1)
+    total_blocks_plane = (hblk_total * wblk) * (world if args.weak else 1)
 
     full, quant = synth_input_gpu(torch, pkg, size, args.jpeg_quality, dev)
     pristine = full[r0:r1].contiguous()
-    cpu_sample = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_sample = full.cpu().numpy()
-    band_for_verify = full[: min(16, hblk_total)].contiguous().cpu().numpy() if (args.verify and rank == 0) else None
+    nsteps = c["nsteps"]
+    batch = _batch_size(args, nsteps, pristine.numel() * 2)
     edge_checks = []
-    if args.verify and world > 1 and not args.weak:
+    if c["verify"] and c["sharded"]:
         # the two block rows on our side of each band edge, checked against the oracle run on a
         # crop around the edge (a block after n iterations depends only on blocks within n of it)
         m = args.niter + 2
@@ -193,21 +352,20 @@ def main():
                                        (r0, (r0, r0 + 2)) if topo.up is not None else None) if e]:
             lo, hi = max(0, edge - 2 - m), min(hblk_total, edge + 2 + m)
             edge_checks.append((lo, mine, full[lo:hi].contiguous().cpu().numpy()))
+    keep_full = full if (rank == 0 and (c["verify"] or not args.no_cpu_baseline)) else None
     del full
 
-    nsteps = args.steps + args.warmup
-    work = [pristine.clone() for _ in range(nsteps)]          # one resident plane per step
-    eng = bands.HipBandEngine(hip, torch, work[0], quant, flags, luma=1, device=dev)
+    work = [[pristine.clone() for _ in range(batch)] for _ in range(nsteps)]   # resident inputs, one set per step
+    eng = bands.HipBandEngine(hip, torch, work[0][0], quant, flags, luma=1, device=dev)
     stream = torch.cuda.current_stream()
     ev_pairs = []
-    sharded = topo.up is not None or topo.down is not None
-
-    comm = eng.comm_scope() if (sharded and args.overlap) else None
+    is_band = topo.up is not None or topo.down is not None
+    comm = eng.comm_scope() if (is_band and args.overlap) else None
     exch = bands.exchange_halo_dist if args.backend == "nccl" else bands.exchange_halo_dist_hostcopy
 
-    def step(coef, timed):
+    def one_plane(coef, timed):
         eng.rebind(coef)
-        if sharded:
+        if is_band:
             # default: pass A, halo exchange, pass B in stream order (bands.run_band); --overlap:
             # bands.run_band_overlapped.  Per-kernel event timing is an N = 1 matter (roofline is
             # reported there)
@@ -226,93 +384,180 @@ def main():
                 e1.record(stream)
                 ev_pairs.append((e0, e1))
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     for i in range(args.warmup):
-        step(work[i], False)
-    fence()
+        for p in work[i]:
+            one_plane(p, False)
+    _fence(torch, dist, world)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(work[args.warmup + i], True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    edges_ok = None
-    if args.verify and world > 1 and not args.weak:
+        for bi, p in enumerate(work[args.warmup + i]):
+            one_plane(p, bi == 0)                        # HIP events around the first plane's launches of every step
+    _fence(torch, dist, world)
+    elapsed = _max_over_ranks(torch, dist, world, time.perf_counter() - t0, dev, args.backend)
+    assert not eng.bad_coef(), "range check tripped on synthetic input"
+    last = work[-1][-1]                                   # the last plane of the last timed step
+
+    res = dict(elapsed=elapsed, batch=batch, total_blocks=total_blocks_plane * batch, blocks_per_gpu=hblk * wblk,
+               kernel=f"qs_smooth_plane_kernel<{'true' if flags & 1 else 'false'}>", kernel_blocks=hblk * wblk,
+               kern_ms=float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else None,
+               kernel_launches=len(ev_pairs),
+               workload=f"{size}x{size} luma plane ({hblk_total * wblk} blocks)")
+    if c["verify"] and c["sharded"]:
         from oracle.oracle import Oracle
-        got = work[-1].cpu().numpy()                      # the last step's result, this rank's band
+        got = last.cpu().numpy()
         ok = True
         for lo, (a0, a1), crop in edge_checks:
             want = Oracle().do_quantsmooth([crop], [quant], flags, args.niter, threads=0)["coefs"][0]
             ok &= bool(np.array_equal(got[a0 - r0:a1 - r0], want[a0 - lo:a1 - lo]))
         flag = torch.tensor([int(ok)], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        edges_ok = bool(flag.item())
-    assert not eng.bad_coef(), "range check tripped on synthetic input"
+        res["verify_band_edges_ok"] = bool(flag.item())
+    if c["verify"]:
+        # N = 1: top / middle / bottom of the whole plane.  N > 1: every rank holds one band; rank 0
+        # checks the top rows of the image here and the band edges were checked above.
+        from oracle.oracle import Oracle, RowSource, verify_bands
+        if rank == 0:
+            if c["sharded"]:
+                n = min(16, hblk)
+                crop = keep_full[: min(hblk_total, n + args.niter + 1)].cpu().numpy()
+                want = Oracle().do_quantsmooth([crop], [quant], flags, args.niter, threads=0)["coefs"][0][:n]
+                bad = int((last[:n].cpu().numpy() != want).any(axis=2).sum())
+                detail = [dict(where="top", row0=0, row1=n, bad_blocks=bad)]
+            else:
+                detail = verify_bands(Oracle(), RowSource(keep_full), quant, flags, args.niter, RowSource(last), rows=16)
+            res["verify_detail"] = detail
+            res["verify_rows"] = sum(d["row1"] - d["row0"] for d in detail)
+            res["verify_ok"] = all(d["bad_blocks"] == 0 for d in detail)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        host_plane = keep_full.cpu().numpy()
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
-    band_blocks = hblk * wblk
+        def run_sample(impl, threads, frac):
+            rows = max(8, min(hblk_total, int(round(hblk_total * frac))))
+            crop = np.ascontiguousarray(host_plane[:rows])
+            impl.do_quantsmooth([crop], [quant], flags, args.niter, threads=threads)
+            return rows * wblk
+        res["cpu_baseline"] = cpu_baseline(
+            args, run_sample, hblk_total * wblk, "blocks",
+            lambda f: f"the top {max(8, min(hblk_total, int(round(hblk_total * f))))} of {hblk_total} block rows of the same plane")
+    return res
 
-    if rank == 0:
-        value = total_blocks * args.steps / elapsed
-        if not ev_pairs:   # sharded run: no per-kernel events; derive from the step time (comm included)
-            kern_ms = elapsed / args.steps / args.niter * 1e3
-        achieved_gbs = band_blocks * ALGO_BYTES_PER_BLOCK_ITER / (kern_ms * 1e-3) / 1e9
-        achieved_tf = band_blocks * FLOP_PER_BLOCK_ITER[flags & 1] / (kern_ms * 1e-3) / 1e12
-        traffic = None
-        pmc = ROOT / "profiles" / "pmc_traffic.json"
-        if pmc.exists():
-            try:
-                traffic = json.loads(pmc.read_text()).get(f"q{args.quality}_{size}")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "8x8 blocks/s at q=%d niter=%d" % (args.quality, args.niter),
-            "value": value, "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "mpixels_per_s": value * 64 / 1e6,
-            "config": {"workload": f"{size}x{size} luma plane ({hblk_total * wblk} blocks), jpegqs --quality {args.quality} "
-                                   f"(flags={flags}) --niter {args.niter}, synthetic JPEG-quality-{args.jpeg_quality} coefficients",
-                       "sharding": "none" if world == 1 else f"{world} block-row bands, 1-pixel-row halo over "
-                                                               f"{'RCCL' if args.backend == 'nccl' else 'gloo (host-staged)'} per iteration, "
-                                                               + ("exchange overlapped with the interior rows" if args.overlap
-                                                                  else "exchange between pass A and pass B in stream order"),
-                       "blocks_per_gpu": band_blocks, **({"comm_note": comm_note} if comm_note else {})},
-            "roofline": {"bound": "hbm", "kernel": "qs_smooth_plane_kernel", "achieved": achieved_gbs,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": band_blocks * ALGO_BYTES_PER_BLOCK_ITER,
-                         "note": "kernel is FP32-VALU-bound (~290 flop/B); see roofline_valu"},
-            "roofline_valu": {"bound": "fp32-valu (separate mul/add, FMA forbidden by bit-exactness)",
-                              "achieved": achieved_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": achieved_tf / VALU_PEAK_TFLOPS,
-                              "flop_per_block_iter": FLOP_PER_BLOCK_ITER[flags & 1]},
-        }
-        if cpu_sample is not None:
-            out["cpu_baseline"] = cpu_baseline(pkg, args, cpu_sample, quant, flags)
-            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        if edges_ok is not None:
-            out["verify_band_edges_ok"] = edges_ok
-        if band_for_verify is not None:
-            from oracle.oracle import Oracle
-            n = band_for_verify.shape[0]
-            want = Oracle().do_quantsmooth([band_for_verify], [quant], flags, args.niter, threads=0)["coefs"][0]
-            got = work[-1][: n].cpu().numpy()
-            safe = n - args.niter - 1
-            out["verify_rows"] = safe
-            out["verify_ok"] = bool(np.array_equal(got[:safe], want[:safe]))
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+
+# ---------------------------------------------------------------------------
+# 4:2:0 YCbCr with the cross-component stages (BASELINE configs[4])
+
+def run_colour(c):
+    args, torch, dist, pkg, hip, B = c["args"], c["torch"], c["dist"], c["pkg"], c["hip"], c["bands"]
+    flags, size, world, rank, dev = c["flags"], c["size"], c["world"], c["rank"], c["dev"]
+    hby, hbc, wby = size // 8, size // 16, size // 8
+    coefs, quants = synth_colour_gpu(torch, pkg, size, args.jpeg_quality, dev)
+    hsamp, vsamp = [2, 1, 1], [2, 1, 1]
+    if c["sharded"]:
+        y0, y1, c0, c1 = B.colour_band_split(hby, hbc, 2, world)[rank]
+        topo = B.BandTopology(rank, world, c0, c1)
+    else:
+        y0, y1, c0, c1 = 0, hby, 0, hbc
+        topo = B.BandTopology(0, 1, 0, hbc)
+    mine = [coefs[0][y0:y1].contiguous(), coefs[1][c0:c1].contiguous(), coefs[2][c0:c1].contiguous()]
+    nsteps = c["nsteps"]
+    batch = _batch_size(args, nsteps, sum(t.numel() for t in mine) * 2 * 3)    # (+ the upsampled outputs)
+    total_blocks_img = (hby * wby + 2 * hbc * (wby // 2)) * (world if args.weak else 1)
+    small = size <= 1024                                    # small enough for the oracle to do the whole image
+    keep = coefs if ((rank == 0 or (small and c["sharded"])) and (c["verify"] or not args.no_cpu_baseline)) else None
+    del coefs
+    work = [[[t.clone() for t in mine] for _ in range(batch)] for _ in range(nsteps)]
+    stream = torch.cuda.current_stream()
+    ev_pairs = []
+    is_band = topo.up is not None or topo.down is not None
+
+    xrows = B.exchange_rows_dist if args.backend == "nccl" else B.exchange_rows_dist_hostcopy
+
+    def exchange(rows_list):
+        if is_band:
+            xrows(rows_list[0], topo, dist)
+    # one band object (constants, planes, low-res luma), re-pointed at each resident image
+    band = B.ColourBand(hip, torch, work[0][0], quants, hsamp, vsamp, (size, size), flags, args.niter, topo, dev)
+    band.chroma_row0 = c0
+    timing = [False]
+    plain_smooth = band.eng[0].smooth
+
+    def luma_smooth(final_clamp):                           # HIP events around the luma recovery launches
+        if not timing[0]:
+            return plain_smooth(final_clamp)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream); plain_smooth(final_clamp); e1.record(stream)
+        ev_pairs.append((e0, e1))
+    band.eng[0].smooth = luma_smooth
+
+    def one_image(cf, timed):
+        for ci in range(3):
+            band.eng[ci].rebind(cf[ci])
+        timing[0] = timed
+        B.run_colour_bands([band], exchange)
+
+    for i in range(args.warmup):
+        for cf in work[i]:
+            one_image(cf, False)
+    _fence(torch, dist, world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        for bi, cf in enumerate(work[args.warmup + i]):
+            one_image(cf, bi == 0 and not is_band)
+    _fence(torch, dist, world)
+    elapsed = _max_over_ranks(torch, dist, world, time.perf_counter() - t0, dev, args.backend)
+    for e in band.eng:
+        assert not e.bad_coef(), "range check tripped on synthetic input"
+    res = dict(elapsed=elapsed, batch=batch, total_blocks=total_blocks_img * batch,
+               blocks_per_gpu=sum(int(t.shape[0] * t.shape[1]) for t in mine),
+               kernel=f"qs_smooth_plane_kernel<{'true' if flags & 1 else 'false'}> (luma plane)",
+               kernel_blocks=(y1 - y0) * wby,
+               kern_ms=float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else None,
+               kernel_launches=len(ev_pairs),
+               workload=f"{size}x{size} 4:2:0 YCbCr image ({hby * wby} + 2 x {hbc * (wby // 2)} blocks)")
+    if c["verify"] and c["sharded"] and small:
+        # functional runs of the sharded path: every rank checks its whole band against the oracle's
+        # result for the whole image
+        from oracle.oracle import Oracle
+        want = Oracle().do_quantsmooth([t.cpu().numpy() for t in keep], quants, flags, args.niter, threads=0,
+                                       hsamp=hsamp, vsamp=vsamp, colorspace=3, image_size=(size, size))
+        ok = bool(np.array_equal(band.eng[0].coef.cpu().numpy(), want["coefs"][0][y0:y1]))
+        for ci in (1, 2):
+            if want["up"]:
+                ok &= bool(np.array_equal(band.up[ci - 1].cpu().numpy(), want["coefs"][ci][y0:y1]))
+            else:
+                ok &= bool(np.array_equal(band.eng[ci].coef.cpu().numpy(), want["coefs"][ci][c0:c1]))
+        flag = torch.tensor([int(ok)], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        res["verify_band_edges_ok"] = bool(flag.item())
+    if (c["verify"] or not args.no_cpu_baseline) and rank == 0:
+        # top crop: a block's result depends on blocks within about 2 * niter + 2 chroma block rows
+        # (luma iterations feed the predictor through the low-res luma plane, then the chroma iterations)
+        from oracle.oracle import Oracle
+        rows_c = min(hbc, 8)
+        crop_c = min(hbc, rows_c + 2 * args.niter + 3)
+        crop = [keep[0][: crop_c * 2].cpu().numpy(), keep[1][:crop_c].cpu().numpy(), keep[2][:crop_c].cpu().numpy()]
+        kw = dict(hsamp=hsamp, vsamp=vsamp, colorspace=3, image_size=(size, crop_c * 16))
+        if c["verify"]:
+            want = Oracle().do_quantsmooth(crop, quants, flags, args.niter, threads=0, **kw)
+            got = [band.eng[0].coef[: rows_c * 2].cpu().numpy()]
+            for ci in (1, 2):
+                got.append((band.up[ci - 1][: rows_c * 2] if want["up"] else band.eng[ci].coef[:rows_c]).cpu().numpy())
+            detail = []
+            for ci in range(3):
+                w = want["coefs"][ci][: got[ci].shape[0]]
+                detail.append(dict(where=f"top, component {ci}", row0=0, row1=int(got[ci].shape[0]),
+                                   bad_blocks=int((got[ci] != w).any(axis=2).sum())))
+            res["verify_detail"] = detail
+            res["verify_rows"] = rows_c
+            res["verify_ok"] = all(d["bad_blocks"] == 0 for d in detail)
+        if world == 1 and not args.no_cpu_baseline:
+            nblk = sum(int(a.shape[0] * a.shape[1]) for a in crop)
+
+            def run_sample(impl, threads, frac):
+                impl.do_quantsmooth(crop, quants, flags, args.niter, threads=threads, **kw)
+                return nblk
+            res["cpu_baseline"] = cpu_baseline(args, run_sample, nblk, "blocks",
+                                               lambda f: f"the top {crop_c} chroma block rows of the same image ({nblk} blocks)")
+    return res
 
 
 if __name__ == "__main__":

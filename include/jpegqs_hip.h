@@ -80,9 +80,30 @@ int qs_hip_do_quantsmooth(qs_hip_job *job, int flags, int niter, int progprec,
  * the batch as a whole could not run (bad arguments, no device).  Not part of the
  * reference API: an addition for callers that serve many images. */
 int qs_hip_do_quantsmooth_batch(qs_hip_job *const *jobs, int njobs, int flags, int niter, int *results);
+
+/* ---- several GPUs, one host process (the reference's counterpart is the
+ * OpenMP row split INSIDE do_quantsmooth, reference quantsmooth.h:2587-2640) ----
+ * A job of at least 512k blocks (QS_HIP_SHARD_MIN_BLOCKS) without a progress callback is cut
+ * into one block-row band per device; each band stays on its GPU for the whole job and pulls one
+ * pixel row per component from each neighbouring band after every pass A (hipMemcpyPeerAsync over
+ * xGMI).  Bit-exact with the one-device result.  Both the independent-component flags (CLI
+ * --quality 3/4) and the coupled YCbCr flags (--quality 5/6) are covered; anything else runs on
+ * the current device.  The device list: qs_hip_set_devices(), else the environment variable
+ * QS_HIP_DEVICES ("all", or ordinals such as "0,1,2,3"), else every visible device; fewer than
+ * two entries = no sharding.  An ordinal may repeat (several bands on one GPU: how the route is
+ * tested on a one-GPU box).  n = 0 returns to the default. */
+int qs_hip_set_devices(const int *devices, int n);
+/* the same job, cut over exactly these devices whatever its size (QS_HIP_ENOTSUP when the
+ * flag / table combination has no sharded route; a progress callback is not available here) */
+int qs_hip_do_quantsmooth_sharded(qs_hip_job *job, int flags, int niter, const int *devices, int ndev);
+
 void qs_hip_free(void *p);
-/* the job layer keeps freed device buffers (up to 6 GiB), pinned staging buffers (up to
- * 2 GiB) and HIP streams in process-wide caches; this returns them to the driver.  (It also
+/* the job layer keeps freed device buffers (up to 6 GiB per device), pinned staging buffers (up
+ * to 2 GiB) and HIP streams in process-wide caches, each entry tied to the device it was created
+ * on and handed out only to callers whose current HIP device is that one (a host thread may
+ * hipSetDevice() to any GPU before calling the job layer); this returns them to the driver.
+ * qs_hip_do_quantsmooth_batch keeps at most QS_HIP_GROUP_WINDOW (6) groups of about 200k blocks
+ * in flight, so its memory does not grow with the size of the batch.  (It also
  * starts eight helper threads on first use, for the host side of large transfers; they
  * sleep between jobs and live until the process ends.) */
 void qs_hip_release_cache(void);
@@ -132,7 +153,9 @@ typedef struct {
 	int16_t *d_coef;
 	uint8_t *d_plane;
 	int32_t *d_status;
-	int32_t wblk, hblk, luma, reserved;
+	int32_t wblk, hblk, luma;
+	int32_t band;  /* 0: a whole plane.  Bit 0 / bit 1: the plane is a band of block rows whose top /
+	                * bottom apron row is a halo row received from the neighbouring band (pass A leaves it alone) */
 } qs_hip_plane_ref;
 int qs_hip_idct_planes(const qs_hip_plane_ref *refs, int n, int first, void *stream);
 int qs_hip_smooth_planes(const qs_hip_plane_ref *refs, int n, int flags, int final_clamp, void *stream);

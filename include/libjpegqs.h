@@ -67,6 +67,13 @@ typedef struct {
 JPEGQS_ATTR
 int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpegqs_control_t *opts);
 
+/* Not in the reference: why the calling thread's last do_quantsmooth() returned non-zero.
+ * 0 = for the reference's own reasons (cancelled by progress(), rejected tables/coefficients: the
+ * image is still decodable); < 0 = the GPU back end failed (no HIP device, out of memory, launch
+ * error -- a QS_HIP_E* code of jpegqs_hip.h) and the image was left untouched. */
+JPEGQS_ATTR
+int jpegqs_hip_backend_status(void);
+
 #ifndef TRANSCODE_ONLY
 /* Decode-mode wrappers: replace jpeg_start_decompress()/jpeg_finish_decompress()
  * so that jpeg_read_scanlines() delivers the smoothed image. */

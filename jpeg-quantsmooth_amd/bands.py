@@ -404,6 +404,27 @@ def exchange_rows_dist(rows: PlaneRows, topo: BandTopology, dist) -> None:
             w.wait()
 
 
+def exchange_rows_dist_hostcopy(rows: PlaneRows, topo: BandTopology, dist) -> None:
+    """exchange_rows_dist staged through host memory (gloo has no device-buffer p2p): functional
+    tests of the multi-process colour path on a box where RCCL cannot run (one GPU)"""
+    import torch
+    h = rows.hblk * 8
+    ops, recvs = [], []
+    for nbr, src_y, dst_y in ((topo.up, 0, -1), (topo.down, h - 1, h)):
+        if nbr is None:
+            continue
+        out = rows.row(src_y).to("cpu")                 # stream-ordered after the producing kernel (blocking copy)
+        buf = torch.empty_like(out)
+        ops.append(dist.P2POp(dist.isend, out, nbr))
+        ops.append(dist.P2POp(dist.irecv, buf, nbr))
+        recvs.append((dst_y, buf))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for dst_y, buf in recvs:
+        rows.row(dst_y).copy_(buf)
+
+
 def colour_band_split(hblk_y, hblk_c, vs, world):
     """[(luma r0, r1, chroma r0, r1)] per rank; cut on chroma block rows"""
     out = []

@@ -123,7 +123,17 @@ int main(int argc, char **argv) {
 
 	(void)jpeg_read_header(&src, TRUE);
 	coefs = jpeg_read_coefficients(&src);
-	do_quantsmooth(&src, coefs, &opts);
+	/* The reference ignores the return value (its do_quantsmooth cannot fail, and a cancelled or
+	 * rejected run still leaves a decodable image, quantsmooth.c:550).  The GPU back end can fail:
+	 * then nothing was processed, and writing the input back out with exit code 0 would hand
+	 * scripts an unsmoothed file as a success. */
+	if (do_quantsmooth(&src, coefs, &opts) && jpegqs_hip_backend_status() < 0) {
+		fprintf(stderr, "%s: GPU back end failed (code %d), no output written\n", prog, jpegqs_hip_backend_status());
+		jpeg_destroy_compress(&dst);
+		jpeg_destroy_decompress(&src);
+		if (in != stdin) fclose(in);
+		return 3;
+	}
 
 	jpeg_copy_critical_parameters(&src, &dst);
 	if (optimize) dst.optimize_coding = TRUE;

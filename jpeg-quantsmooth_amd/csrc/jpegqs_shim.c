@@ -36,6 +36,15 @@ EXTERN(void) jinit_upsampler JPP((j_decompress_ptr));
 EXTERN(void) jinit_color_deconverter JPP((j_decompress_ptr));
 #endif
 
+/* Why the last do_quantsmooth() of this thread returned non-zero.  The reference's return value
+ * only knows "stop" (cancelled / rejected input, the image stays decodable); a GPU back end can
+ * also FAIL (no device, out of memory, launch error), in which case nothing was processed.  The
+ * reference API has no room for that distinction, so it is an extra query (not in the
+ * reference): 0 = the call did what the reference would have done, otherwise a negative
+ * QS_HIP_E* code.  The jpegqs CLI uses it to exit non-zero instead of writing an unprocessed file. */
+static __thread int qs_backend_status = 0;
+int jpegqs_hip_backend_status(void) { return qs_backend_status; }
+
 static double now_ms(void) {
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -71,8 +80,10 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 	if (flags & JPEGQS_INFO_CPU) logfmt("SIMD type: hip/gfx950 (%d device(s))\n", qs_hip_device_count());
 	if (flags & JPEGQS_INFO_TIME) t0 = now_ms();
 
+	qs_backend_status = 0;
 	if (srcinfo->num_components < 1 || srcinfo->num_components > QS_HIP_MAXC) {
 		logfmt("jpegqs-hip: unsupported component count %d\n", srcinfo->num_components);
+		qs_backend_status = QS_HIP_EINVAL;
 		return 1;
 	}
 
@@ -97,11 +108,12 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 			for (i = 0; i < DCTSIZE2; i++) job.quant[ci][i] = comp->quant_table->quantval[i];
 		if (comp->width_in_blocks == 0 || comp->height_in_blocks == 0) {
 			logfmt("jpegqs-hip: empty component %d\n", ci);
+			qs_backend_status = QS_HIP_EINVAL;
 			goto fail_free;
 		}
 		rowbytes = (size_t)comp->width_in_blocks * sizeof(JBLOCK);
 		job.coef[ci] = (int16_t*)malloc(rowbytes * comp->height_in_blocks);
-		if (!job.coef[ci]) { logfmt("jpegqs-hip: out of memory\n"); goto fail_free; }
+		if (!job.coef[ci]) { logfmt("jpegqs-hip: out of memory\n"); qs_backend_status = QS_HIP_ENOMEM; goto fail_free; }
 		for (blk_y = 0; blk_y < comp->height_in_blocks; blk_y++) {
 			JBLOCKARRAY buf = (*srcinfo->mem->access_virt_barray)
 					((j_common_ptr)srcinfo, coef_arrays[ci], blk_y, 1, FALSE);
@@ -127,6 +139,7 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 	if (ret < 0) {
 		/* no CPU fallback by design: report and leave the image untouched */
 		logfmt("jpegqs-hip: %s\n", qs_hip_last_error());
+		qs_backend_status = ret;
 		goto fail_free;
 	}
 

@@ -55,7 +55,12 @@ struct QsPlaneRef {
   uint8_t* plane;        // pixel plane with apron
   int32_t* status;       // range-check flag (pass A, first iteration)
   int32_t wblk, hblk, pitch;
-  int32_t rebalance;     // pass B: run the rebalance step on this plane
+  int32_t mode;          // QS_PLANE_* bits
+};
+enum {
+  QS_PLANE_REBALANCE = 1,  // pass B: run the rebalance step on this plane
+  QS_PLANE_REP_TOP = 2,    // pass A: the y = -1 apron row is a replica of row 0 (image edge) ...
+  QS_PLANE_REP_BOT = 4     // ... / the y = h apron row of row h-1; clear = halo row owned by the neighbouring band
 };
 struct QsPlaneSet {
   int32_t n, pad;

@@ -6,7 +6,7 @@
 #include <list>
 #include <chrono>
 
-#include "qs_xfer.h"
+#include "qs_jobint.h"
 
 // ---------------------------------------------------------------------------
 // job layer
@@ -29,6 +29,9 @@
 // Device buffers come from a small process-wide cache (hipMalloc/hipFree of
 // 100+ MiB cost milliseconds each); qs_hip_release_cache() empties it.
 
+using namespace qsx;
+using namespace qsj;
+
 namespace {
 
 struct Comp {            // per-component device state (kept until the job ends)
@@ -40,19 +43,17 @@ struct Comp {            // per-component device state (kept until the job ends)
   hipStream_t stream = nullptr;
 };
 
-enum { JOB_RERUN_CAREFUL = -1000 };
+}  // namespace
 
-static double wall_ms() {
+double qsj::wall_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-static bool trace_on() { static const bool on = getenv("QS_HIP_TRACE") != nullptr; return on; }
+bool qsj::trace_on() { static const bool on = getenv("QS_HIP_TRACE") != nullptr; return on; }
 
-static int run_job(qs_hip_job* job, int flags, int niter, int progprec,
-                   qs_hip_progress_fn progress, void* userdata, bool eager) {
-  int need_lowres = 0, stop = 0;
-  if ((flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV)) && job->colorspace == 3 && job->ncomp >= 3 &&
-      job->hsamp[1] == 1 && job->vsamp[1] == 1 && job->hsamp[2] == 1 && job->vsamp[2] == 1)
-    need_lowres = 1;                                     // reference :2447-2453
+int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
+                 qs_hip_progress_fn progress, void* userdata, bool eager) {
+  int stop = 0;
+  const int need_lowres = job_needs_lowres(job, flags);  // reference :2447-2453
 
   // streams/events are pooled too (creating three streams costs ~1 ms)
   StreamLease lease;
@@ -80,6 +81,9 @@ static int run_job(qs_hip_job* job, int flags, int niter, int progprec,
   bool have_yfull = false, have_llow = false;
   int16_t* up_host[2] = { nullptr, nullptr };
   struct UpFree { int16_t** p; bool keep; ~UpFree() { if (!keep) { free(p[0]); free(p[1]); } } } up_free{up_host, false};
+  // declared after every buffer above: on any early return the streams are drained first,
+  // only then do the buffers go back to the shared pools (another thread may take them at once)
+  DrainGuard drain{lease.p};
 
   for (int ci = 0; ci < job->ncomp; ++ci) {
     Comp& C = comp[ci];
@@ -266,17 +270,26 @@ static int run_job(qs_hip_job* job, int flags, int niter, int progprec,
 // range-check flags are read once at the end, a job with a set flag is re-run in
 // the careful order from its untouched host input.
 
-static int comp_rebalance(const qs_hip_job* job, int ci, int flags) {
+int qsj::comp_rebalance(const qs_hip_job* job, int ci, int flags) {
   const int luma = !ci || job->colorspace != 3;                                     // reference :2639
   return !(flags & QS_NO_REBALANCE) && (luma || !(flags & QS_NO_REBALANCE_UV));       // :1567-1568
 }
 
-static bool job_needs_lowres(const qs_hip_job* job, int flags) {                     // reference :2447-2453
-  return (flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV)) && job->colorspace == 3 && job->ncomp >= 3 &&
+// The luma/chroma coupling of JOINT_YUV / UPSAMPLE_UV (reference :2447-2453).  libjpeg only ever
+// reports JCS_YCbCr with exactly three components; the flat ABI could be handed four, for which the
+// reference's coef_up[ci - 1] indexing has no meaning (two replacement arrays exist), so the
+// coupling is tied to ncomp == 3 here.
+bool qsj::job_needs_lowres(const qs_hip_job* job, int flags) {
+  return (flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV)) && job->colorspace == 3 && job->ncomp == 3 &&
          job->hsamp[1] == 1 && job->vsamp[1] == 1 && job->hsamp[2] == 1 && job->vsamp[2] == 1;
 }
 
-static bool job_fusable(const qs_hip_job* job, int flags) {
+size_t qsj::env_size(const char* name, size_t dflt) {
+  const char* v = getenv(name);
+  const long long n = v ? atoll(v) : 0;
+  return n > 0 ? (size_t)n : dflt;
+}
+bool qsj::job_fusable(const qs_hip_job* job, int flags) {
   static const bool off = getenv("QS_HIP_NO_FUSE") != nullptr;
   if (off || (flags & QS_LOW_QUALITY) || job_needs_lowres(job, flags)) return false;
   for (int ci = 0; ci < job->ncomp; ++ci) {
@@ -288,6 +301,7 @@ static bool job_fusable(const qs_hip_job* job, int flags) {
   return true;
 }
 
+namespace {
 // One device plane of a set: a whole component, or a band of block rows of a very large
 // one (rows [src_row0, src_row0 + hb) of the source, of which [keep0, keep1) are results:
 // the rest is halo, see split_rows).
@@ -302,10 +316,12 @@ struct FGroup {
   Download down;                          // results on their way back
   hipStream_t s = nullptr;
   size_t blocks = 0, coef_bytes = 0;
-};
-struct DrainGuard {                       // error paths: nothing may be freed while the streams still run
-  Streams* st;
-  ~DrainGuard() { for (auto& x : st->s) (void)hipStreamSynchronize(x); }
+  // everything queued on the group's stream has completed: give the arenas back
+  void release_transients(bool keep_stage) {
+    coef.release(); px.release(); cst.release(); status.release();
+    hstatus.release(); down.reset();
+    if (!keep_stage) stage.release();
+  }
 };
 
 // a group of >= 3 waves per SIMD runs at the streaming rate; smaller groups let the upload of one
@@ -317,11 +333,6 @@ static const size_t kGroupBlocks = (size_t)200 << 10;
 // carries n extra block rows on each cut side (recomputed, not copied back): bit-exact.
 // (QS_HIP_SPLIT_BLOCKS / QS_HIP_BAND_BLOCKS override the two sizes: the tests use them to run
 // the band logic on small images.)
-static size_t env_size(const char* name, size_t dflt) {
-  const char* v = getenv(name);
-  const long long n = v ? atoll(v) : 0;
-  return n > 0 ? (size_t)n : dflt;
-}
 static const size_t kSplitBlocks = env_size("QS_HIP_SPLIT_BLOCKS", (size_t)512 << 10),
                     kBandBlocks = env_size("QS_HIP_BAND_BLOCKS", (size_t)256 << 10);
 
@@ -331,6 +342,7 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
   std::list<FGroup> groups;
   DrainGuard drain{lease.p};
   const double t_start = wall_ms();
+  double t_enq = t_start;
 
   // ---- partition into groups (a job never straddles two, unless it is cut into bands)
   int maxj = 0;
@@ -376,10 +388,10 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
   }
   groups.remove_if([](const FGroup& g) { return g.planes.empty(); });   // placeholders left by band jobs
 
-  // ---- enqueue every group: upload, niter x (pass A, pass B), status readback
+  // ---- per group: upload, niter x (pass A, pass B), status readback, download into pinned memory
   const int diag = (flags & QS_DIAGONALS) != 0;
   size_t gi = 0;
-  for (FGroup& G : groups) {
+  auto enqueue = [&](FGroup& G) -> int {
     G.s = lease.p->s[gi++ % 3];
     const int np = (int)G.planes.size();
     size_t coef_bytes = 0, px_bytes = 0;
@@ -421,7 +433,7 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
       R.plane = G.px.as<uint8_t>() + P.px_off;
       R.status = G.status.as<int32_t>() + i;
       R.wblk = P.wb; R.hblk = P.hb; R.pitch = qs_plane_pitch(P.wb);
-      R.rebalance = comp_rebalance(jobs[P.job], P.ci, flags);
+      R.mode = QS_PLANE_REP_TOP | QS_PLANE_REP_BOT | (comp_rebalance(jobs[P.job], P.ci, flags) ? QS_PLANE_REBALANCE : 0);
     }
     for (int i = np; i < QS_MAX_PLANES + 2; ++i) set.wave0[i] = w;
     for (int it = 0; it < niter; ++it) {
@@ -433,34 +445,58 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
     if (!G.hstatus.alloc((size_t)np * sizeof(int32_t))) return qs_fail(QS_HIP_ENOMEM, "out of pinned host memory");
     HIP_TRY(hipMemcpyAsync(G.hstatus.p, G.status.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, G.s));
     HIP_TRY(G.down.issue(G.coef.p, coef_bytes, G.s));       // to pinned memory, right behind the kernels
-  }
-  const double t_enq = wall_ms();
+    // a band job is scattered band by band; without the staging copy of its input (pinned memory
+    // exhausted) nothing could be restored should a later band trip the range check: hold it back
+    if (!G.stage.p) for (int ji : G.jobs) if (split[ji]) defer[ji] = 1;
+    return QS_HIP_OK;
+  };
 
-  // ---- drain group by group; results go back only for jobs whose range check passed.
+  // ---- drain a group; results go back only for jobs whose range check passed.
   // A job cut into bands is scattered band by band before its later bands have been
   // checked: should one of those trip the range check after all (crafted file), the rows
   // already written are restored from the pinned upload staging, which still holds the
-  // original input.  Without that staging copy (pinned memory exhausted) the job's bands
-  // are held back until all of them have been checked.
+  // original input.  Without that staging copy the job's bands are held back until all of
+  // them have been checked.
   auto result_piece = [&](const FPlane& P) {
     const size_t row = (size_t)P.wb * 128;
     return Piece{jobs[P.job]->coef[P.ci] + (size_t)(P.src_row0 + P.keep0) * P.wb * 64,
                  P.coef_off + P.keep0 * row, (size_t)(P.keep1 - P.keep0) * row};
   };
-  for (FGroup& G : groups)
-    if (!G.stage.p) for (int ji : G.jobs) if (split[ji]) defer[ji] = 1;
   std::vector<FGroup*> held;
-  for (FGroup& G : groups) {
+  auto drain_group = [&](FGroup& G) -> int {
     HIP_TRY(G.down.wait_first(G.s));
     const int32_t* hst = static_cast<const int32_t*>(G.hstatus.p);
     for (size_t i = 0; i < G.planes.size(); ++i) if (hst[i]) bad_job[G.planes[i].job] = 1;
-    bool hold = false;
-    for (int ji : G.jobs) hold |= (defer[ji] != 0);
-    if (hold) { held.push_back(&G); continue; }
+    bool hold = false, banded = false;
+    for (int ji : G.jobs) { hold |= (defer[ji] != 0); banded |= (split[ji] != 0); }
+    if (hold) { held.push_back(&G); return QS_HIP_OK; }
     std::vector<Piece> back;
     for (const FPlane& P : G.planes)
       if (!bad_job[P.job]) { back.push_back(result_piece(P)); scattered[P.job] = 1; }
     HIP_TRY(G.down.finish(G.coef.p, back, G.s));
+    // the group's stream work is complete: recycle its device arenas and download staging now, so
+    // that memory in flight is bounded by the window below and not by the size of the batch.  The
+    // upload staging of a band job stays (it is the restore copy): that is one image's worth.
+    G.release_transients(/*keep_stage=*/banded);
+    return QS_HIP_OK;
+  };
+
+  // At most kWindow groups are in flight (about 200k blocks each: ~40 MiB of device memory and
+  // ~50 MiB of pinned staging per group).
+  static const size_t kWindow = env_size("QS_HIP_GROUP_WINDOW", 6);
+  {
+    std::deque<FGroup*> inflight;
+    for (FGroup& G : groups) {
+      if (inflight.size() >= kWindow) {
+        if (int r = drain_group(*inflight.front())) return r;
+        inflight.pop_front();
+      }
+      if (int r = enqueue(G)) return r;
+      inflight.push_back(&G);
+    }
+    t_enq = wall_ms();
+    for (FGroup* G : inflight)
+      if (int r = drain_group(*G)) return r;
   }
   for (FGroup* G : held) {
     std::vector<Piece> back;
@@ -495,16 +531,21 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
   return QS_HIP_OK;
 }
 
-}  // namespace
+}  // namespace (fused route)
 
 extern "C" void qs_hip_release_cache(void) {
   std::lock_guard<std::mutex> lk(g_cache_mu);
-  for (auto& c : g_cache) (void)hipFree(c.p);
+  const int cur = current_device();
+  for (auto& c : g_cache) {                                  // every device's blocks, each under its own device
+    if (c.dev != current_device()) (void)hipSetDevice(c.dev);
+    (void)hipFree(c.p);
+  }
   g_cache.clear();
-  for (auto* sp : g_stream_pool) delete sp;
+  for (auto* sp : g_stream_pool) delete sp;                  // (~Streams switches to the owning device itself)
   g_stream_pool.clear();
   for (auto& c : PinnedBuf::pool()) (void)hipHostFree(c.p);
   PinnedBuf::pool().clear();
+  if (cur != current_device()) (void)hipSetDevice(cur);
 }
 
 // validation and the reference's early-outs; returns 1 when there is work to do,
@@ -512,9 +553,15 @@ extern "C" void qs_hip_release_cache(void) {
 static int prepare_job(qs_hip_job* job, int flags, int* niter) {
   if (!job || job->ncomp < 1 || job->ncomp > QS_HIP_MAXC)
     return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: bad job");
-  for (int ci = 0; ci < job->ncomp; ++ci)
+  for (int ci = 0; ci < job->ncomp; ++ci) {
     if (!job->coef[ci] || job->wblk[ci] <= 0 || job->hblk[ci] <= 0)
       return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: component %d has no data", ci);
+    if (job->hsamp[ci] < 1 || job->hsamp[ci] > 4 || job->vsamp[ci] < 1 || job->vsamp[ci] > 4)   // JPEG: 1..4
+      return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: component %d has sampling factors %dx%d",
+                     ci, job->hsamp[ci], job->vsamp[ci]);
+    if ((long long)job->wblk[ci] * job->hblk[ci] > (1ll << 27))     // 65500 px / 8 squared is 2^26: int block indices are safe
+      return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: component %d is too large", ci);
+  }
   job->up_wblk = job->up_hblk = 0; job->coef_up[0] = job->coef_up[1] = nullptr;
   job->out_hsamp0 = job->hsamp[0]; job->out_vsamp0 = job->vsamp[0];
   if (*niter < 0) *niter = 0;
@@ -530,6 +577,15 @@ static int do_quantsmooth_impl(qs_hip_job* job, int flags, int niter, int progpr
   if (qs_hip_device_count() <= 0)
     return qs_fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
 
+  if (!progress) {                                             // several GPUs and a job worth spreading over them
+    const std::vector<int> devs = shard_devices_for(job, flags, niter);
+    if (!devs.empty()) {
+      int r = run_sharded(job, flags, niter, devs);
+      if (r == JOB_RERUN_CAREFUL)
+        r = run_job(job, flags, niter, progprec, progress, userdata, /*eager=*/false);
+      return r;
+    }
+  }
   if (!progress && job_fusable(job, flags)) {
     int result = QS_HIP_ENODEV;
     qs_hip_job* one[1] = { job };
@@ -551,7 +607,9 @@ static int do_quantsmooth_batch_impl(qs_hip_job* const* jobs, int njobs, int fla
     const int todo = prepare_job(jobs[j], flags, &n1);
     results[j] = todo < 0 ? todo : 0;
     if (todo <= 0) continue;
-    (job_fusable(jobs[j], flags) ? fused : single).push_back(j);
+    // a job large enough to be spread over several GPUs goes there on its own
+    const bool fuse = job_fusable(jobs[j], flags) && shard_devices_for(jobs[j], flags, n1).empty();
+    (fuse ? fused : single).push_back(j);
   }
   if (fused.empty() && single.empty()) return QS_HIP_OK;
   if (qs_hip_device_count() <= 0)
@@ -573,6 +631,24 @@ extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int 
                                      qs_hip_progress_fn progress, void* userdata) {
   try {
     return do_quantsmooth_impl(job, flags, niter, progprec, progress, userdata);
+  } catch (const std::bad_alloc&) {
+    return qs_fail(QS_HIP_ENOMEM, "out of host memory");
+  } catch (...) {
+    return qs_fail(QS_HIP_ENODEV, "unexpected internal error");
+  }
+}
+
+extern "C" int qs_hip_do_quantsmooth_sharded(qs_hip_job* job, int flags, int niter, const int* devices, int ndev) {
+  try {
+    if (!devices || ndev < 1) return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth_sharded: empty device list");
+    const int todo = prepare_job(job, flags, &niter);
+    if (todo <= 0) return todo;
+    if (qs_hip_device_count() <= 0)
+      return qs_fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+    int r = run_sharded(job, flags, niter, std::vector<int>(devices, devices + ndev));
+    if (r == JOB_RERUN_CAREFUL)
+      r = run_job(job, flags, niter, 0, nullptr, nullptr, /*eager=*/false);
+    return r;
   } catch (const std::bad_alloc&) {
     return qs_fail(QS_HIP_ENOMEM, "out of host memory");
   } catch (...) {

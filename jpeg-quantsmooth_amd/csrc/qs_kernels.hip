@@ -328,7 +328,7 @@ __device__ __forceinline__ int qs_set_find(const QsPlaneSet& set, int w) {
   return lo;
 }
 
-// pass A over a set of planes (whole planes: both apron rows replicated)
+// pass A over a set of planes (whole planes, or bands whose halo-side apron rows are left alone)
 __global__ void __launch_bounds__(256)
 qs_idct_set_kernel(const QsPlaneSet set, int first) {
   const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -337,7 +337,8 @@ qs_idct_set_kernel(const QsPlaneSet set, int first) {
   const QsPlaneRef& r = set.ref[i];
   const int blk = (w - set.wave0[i]) * 64 + (threadIdx.x & 63);
   if (blk >= r.wblk * r.hblk) return;
-  idct_block_to_plane(r.cst, r.coef, r.plane, r.wblk, r.hblk, r.pitch, first, 1, 1, r.status, blk);
+  idct_block_to_plane(r.cst, r.coef, r.plane, r.wblk, r.hblk, r.pitch, first,
+                      r.mode & QS_PLANE_REP_TOP, r.mode & QS_PLANE_REP_BOT, r.status, blk);
 }
 
 // --------------------------------------------------------------------------
@@ -454,6 +455,11 @@ __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >
 #define QS_TAIL_PRIO 1
 #endif
 #define QS_RESIDENT_WG (256 * 3 * 4 / QS_WAVES_PER_WG)
+// measurement only: extra (unused) LDS dwords per wave, to cap how many workgroups a CU holds
+// without touching the code (occupancy experiments: 2400 -> 2 waves per SIMD), see DESIGN.md
+#ifndef QS_LDS_EXTRA
+#define QS_LDS_EXTRA 0
+#endif
 
 #if QS_SKIP_ZERO_WEIGHTS
 #define QS_TERM_OPT(COND, A, B, W) { float d_, t_; \

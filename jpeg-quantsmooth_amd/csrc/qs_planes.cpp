@@ -67,7 +67,8 @@ static int build_plane_set(const qs_hip_plane_ref* refs, int n, int flags, QsPla
     R.cst = static_cast<const QsConsts*>(r.d_consts);
     R.coef = r.d_coef; R.plane = r.d_plane; R.status = r.d_status;
     R.wblk = r.wblk; R.hblk = r.hblk; R.pitch = qs_plane_pitch(r.wblk);
-    R.rebalance = !(flags & QS_NO_REBALANCE) && (r.luma || !(flags & QS_NO_REBALANCE_UV));
+    R.mode = ((!(flags & QS_NO_REBALANCE) && (r.luma || !(flags & QS_NO_REBALANCE_UV))) ? QS_PLANE_REBALANCE : 0) |
+             ((r.band & 1) ? 0 : QS_PLANE_REP_TOP) | ((r.band & 2) ? 0 : QS_PLANE_REP_BOT);
   }
   for (int i = n; i < QS_MAX_PLANES + 2; ++i) set.wave0[i] = w;
   return QS_HIP_OK;

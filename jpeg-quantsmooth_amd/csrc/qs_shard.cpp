@@ -1,0 +1,597 @@
+// qs_shard.cpp -- one job spread over several GPUs from ONE host process, inside the C ABI.
+//
+// The reference parallelises do_quantsmooth() internally (OpenMP over block rows,
+// reference quantsmooth.h:2587-2640); this is the same idea one level up: every component is
+// cut into contiguous block-row BANDS, band d lives on device d for the whole job, and after
+// each pass A a band pulls ONE PIXEL ROW from each neighbouring band into its apron row --
+// the only data the recovery loop reads across a band edge (reference :1396-1401; SURVEY.md
+// section 8e).  Image-edge bands replicate instead (QS_PLANE_REP_TOP / _BOT of the plane set).
+// Bit-exact with the unsharded result: no arithmetic changes, only where a block runs.
+//
+// Mechanics: one stream per band; all launches come from the calling thread, which walks
+// over the devices with hipSetDevice (no helper processes, no launcher).  The halo rows
+// move device-to-device with hipMemcpyPeerAsync over xGMI (a plain device copy when two
+// bands share a GPU), ordered by events:
+//     A[d]  recorded after pass A of band d       -> neighbours wait for it before they pull
+//     X[d]  recorded after band d's pulls          -> neighbours wait for it before their next
+//                                                     pass A overwrites the rows it read
+// The host never waits inside the iteration loop.  Range-check flags are read once at the end
+// (nothing reaches caller memory before that); a set flag sends the job to the careful
+// single-device route, as in qs_job.cpp.
+//
+// Routes: independent components (no JOINT_YUV / UPSAMPLE_UV coupling, no LOW_QUALITY; CLI
+// --quality 3/4, any colour layout) run as ONE plane set per band and pass -- run_sharded_set.
+// Coupled YCbCr jobs (--quality 5/6) are cut on chroma block rows (the luma band is the
+// v_samp-times taller range of the same image rows) and add three one-off exchanges: the
+// low-res luma plane, the refreshed chroma planes -- run_sharded_colour.
+#include <string>
+
+#include "qs_jobint.h"
+
+using namespace qsx;
+using namespace qsj;
+
+namespace {
+
+// block rows [r0, r1) of band `d` of `n` (the arithmetic of bands.py: band_rows)
+static void band_rows(int hblk, int n, int d, int& r0, int& r1) {
+  r0 = (int)((long long)hblk * d / n);
+  r1 = (int)((long long)hblk * (d + 1) / n);
+}
+
+struct BandPlane {       // one component's band on one device
+  int ci = 0, wb = 0, hb = 0, r0 = 0;
+  bool halo_top = false, halo_bot = false;
+  size_t coef_off = 0, px_off = 0, cbytes = 0;
+  int cst = -1;
+};
+
+struct Band {            // one (logical) device
+  int dev = 0, index = 0;
+  Streams* st = nullptr;                 // leased under `dev`
+  hipStream_t s = nullptr;
+  hipEvent_t evA = nullptr, evX = nullptr;
+  std::vector<BandPlane> planes;
+  DevBuf coef, px, cst, status, aux[8];   // aux: route-specific planes (colour route)
+  PinnedBuf stage, hstatus;
+  Download down, down_up[2];
+  std::vector<QsConsts> hc;
+  QsPlaneSet set;
+  bool x_recorded = false;
+};
+
+// All per-device resources of a sharded job.  Destruction order matters: first drain every
+// stream (under its own device), then release buffers, then return the stream sets.
+struct Bands {
+  std::vector<Band> b;
+  int home = 0;
+  explicit Bands(size_t n) : b(n) { home = current_device(); }
+  ~Bands() {
+    for (Band& B : b) {
+      if (!B.st) continue;
+      (void)hipSetDevice(B.dev);
+      for (auto& x : B.st->s) (void)hipStreamSynchronize(x);
+    }
+    for (Band& B : b) {
+      (void)hipSetDevice(B.dev);
+      if (B.evA) (void)hipEventDestroy(B.evA);
+      if (B.evX) (void)hipEventDestroy(B.evX);
+      B.down.reset(); B.down_up[0].reset(); B.down_up[1].reset();
+      B.coef.release(); B.px.release(); B.cst.release(); B.status.release();
+      for (auto& a : B.aux) a.release();
+      if (B.st) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        g_stream_pool.push_back(B.st);
+      }
+    }
+    (void)hipSetDevice(home);
+  }
+};
+
+static int open_bands(Bands& bands, const std::vector<int>& devices) {
+  const int ndev_visible = qs_hip_device_count();
+  for (size_t d = 0; d < devices.size(); ++d) {
+    Band& B = bands.b[d];
+    B.dev = devices[d]; B.index = (int)d;
+    if (B.dev < 0 || B.dev >= ndev_visible) return qs_fail(QS_HIP_EINVAL, "sharded job: no HIP device %d", B.dev);
+    HIP_TRY(hipSetDevice(B.dev));
+    StreamLease lease;                                       // (streams of the now-current device)
+    if (!lease.p) return qs_fail(QS_HIP_ENODEV, "could not create HIP streams on device %d", B.dev);
+    B.st = lease.p; lease.p = nullptr;                       // Bands::~Bands gives it back
+    B.s = B.st->s[0];
+    HIP_TRY(hipEventCreateWithFlags(&B.evA, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&B.evX, hipEventDisableTiming));
+  }
+  // direct xGMI access between neighbouring devices (without it the runtime stages peer copies
+  // through host memory); "already enabled" is not an error
+  for (size_t d = 0; d + 1 < devices.size(); ++d) {
+    const int a = devices[d], c = devices[d + 1];
+    if (a == c) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, a, c) == hipSuccess && can) {
+      (void)hipSetDevice(a); (void)hipDeviceEnablePeerAccess(c, 0); (void)hipGetLastError();
+      (void)hipSetDevice(c); (void)hipDeviceEnablePeerAccess(a, 0); (void)hipGetLastError();
+    }
+  }
+  return QS_HIP_OK;
+}
+
+// dst (on band D's device) <- src (on band S's device), queued on D's stream
+static hipError_t pull(Band& D, void* dst, const Band& S, const void* src, size_t n) {
+  if (D.dev == S.dev) return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, D.s);
+  return hipMemcpyPeerAsync(dst, D.dev, src, S.dev, n, D.s);
+}
+
+// One halo exchange: `nplanes` plane roles at once.  `plane(d, k, &p, &wb, &hb)` yields band d's
+// plane of role k (device pointer, width / height in blocks), or false when the band holds no
+// such plane.  Bands pull the last pixel row of the band above into their y = -1 apron row and
+// the first pixel row of the band below into their y = h apron row.
+// Caller contract: every band's producer kernels for these planes are already queued on its
+// stream; the call records A[d] itself.
+template <class PlaneFn>
+static int exchange(Bands& bands, int nplanes, PlaneFn plane) {
+  const size_t n = bands.b.size();
+  for (Band& B : bands.b) {
+    HIP_TRY(hipSetDevice(B.dev));
+    HIP_TRY(hipEventRecord(B.evA, B.s));
+  }
+  for (size_t d = 0; d < n; ++d) {
+    Band& B = bands.b[d];
+    HIP_TRY(hipSetDevice(B.dev));
+    bool wait_up = false, wait_dn = false;
+    for (int k = 0; k < nplanes; ++k) {
+      uint8_t *mine, *theirs; int wb, hb, wb2, hb2;
+      if (!plane((int)d, k, &mine, &wb, &hb)) continue;
+      const size_t pitch = (size_t)qs_plane_pitch(wb);
+      if (d > 0 && plane((int)d - 1, k, &theirs, &wb2, &hb2)) {
+        Band& U = bands.b[d - 1];
+        if (!wait_up) { HIP_TRY(hipStreamWaitEvent(B.s, U.evA, 0)); wait_up = true; }
+        HIP_TRY(pull(B, mine + qs_hip_plane_row_offset(wb, -1), U, theirs + qs_hip_plane_row_offset(wb2, hb2 * 8 - 1), pitch));
+      }
+      if (d + 1 < n && plane((int)d + 1, k, &theirs, &wb2, &hb2)) {
+        Band& L = bands.b[d + 1];
+        if (!wait_dn) { HIP_TRY(hipStreamWaitEvent(B.s, L.evA, 0)); wait_dn = true; }
+        HIP_TRY(pull(B, mine + qs_hip_plane_row_offset(wb, hb * 8), L, theirs + qs_hip_plane_row_offset(wb2, 0), pitch));
+      }
+    }
+  }
+  for (Band& B : bands.b) {                                  // "my pulls are done" -- see before_overwrite
+    HIP_TRY(hipSetDevice(B.dev));
+    HIP_TRY(hipEventRecord(B.evX, B.s));
+    B.x_recorded = true;
+  }
+  return QS_HIP_OK;
+}
+
+// before band d overwrites planes its neighbours may still be pulling from
+static int before_overwrite(Bands& bands, size_t d) {
+  Band& B = bands.b[d];
+  if (d > 0 && bands.b[d - 1].x_recorded) HIP_TRY(hipStreamWaitEvent(B.s, bands.b[d - 1].evX, 0));
+  if (d + 1 < bands.b.size() && bands.b[d + 1].x_recorded) HIP_TRY(hipStreamWaitEvent(B.s, bands.b[d + 1].evX, 0));
+  return QS_HIP_OK;
+}
+
+// the per-band constant blocks: one per distinct quant table among the band's planes
+static int upload_consts(Band& B, const qs_hip_job* job, int flags) {
+  std::vector<const uint16_t*> qtabs;
+  for (BandPlane& P : B.planes) {
+    const uint16_t* q = job->quant[P.ci];
+    P.cst = -1;
+    for (size_t k = 0; k < qtabs.size() && P.cst < 0; ++k)
+      if (!memcmp(qtabs[k], q, 64 * sizeof(uint16_t))) P.cst = (int)k;
+    if (P.cst < 0) { P.cst = (int)qtabs.size(); qtabs.push_back(q); }
+  }
+  HIP_TRY(B.cst.alloc(std::max<size_t>(1, qtabs.size()) * sizeof(QsConsts)));
+  B.hc.resize(qtabs.size());
+  for (size_t k = 0; k < qtabs.size(); ++k)
+    if (int r = qs_hip_consts_build(&B.hc[k], qtabs[k], flags)) return r;
+  if (!qtabs.empty())
+    HIP_TRY(hipMemcpyAsync(B.cst.p, B.hc.data(), qtabs.size() * sizeof(QsConsts), hipMemcpyHostToDevice, B.s));
+  return QS_HIP_OK;
+}
+
+// arenas + upload of the band's coefficient rows + plane set
+static int stage_band(Band& B, const qs_hip_job* job, int flags) {
+  size_t coef_bytes = 0, px_bytes = 0;
+  for (BandPlane& P : B.planes) {
+    P.cbytes = (size_t)P.wb * P.hb * 128;
+    P.coef_off = coef_bytes; coef_bytes += P.cbytes;
+    P.px_off = px_bytes; px_bytes += (qs_hip_plane_bytes(P.wb, P.hb) + 255) & ~(size_t)255;
+  }
+  const int np = (int)B.planes.size();
+  HIP_TRY(B.coef.alloc(std::max<size_t>(coef_bytes, 64)));
+  HIP_TRY(B.px.alloc(std::max<size_t>(px_bytes, 64)));
+  HIP_TRY(B.status.alloc((size_t)std::max(np, 1) * sizeof(int32_t)));
+  if (int r = upload_consts(B, job, flags)) return r;
+  std::vector<Piece> pieces;
+  for (const BandPlane& P : B.planes)
+    pieces.push_back({job->coef[P.ci] + (size_t)P.r0 * P.wb * 64, P.coef_off, P.cbytes});
+  if (coef_bytes) HIP_TRY(upload_pieces(B.coef.p, pieces, coef_bytes, B.s, B.stage));
+  HIP_TRY(hipMemsetAsync(B.status.p, 0, (size_t)std::max(np, 1) * sizeof(int32_t), B.s));
+
+  QsPlaneSet& set = B.set;
+  memset(&set, 0, sizeof set);
+  set.n = np;
+  int w = 0;
+  for (int i = 0; i < np; ++i) {
+    const BandPlane& P = B.planes[i];
+    set.wave0[i] = w;
+    w += (P.wb * P.hb + 63) / 64;
+    QsPlaneRef& R = set.ref[i];
+    R.cst = B.cst.as<QsConsts>() + P.cst;
+    R.coef = reinterpret_cast<int16_t*>(B.coef.as<char>() + P.coef_off);
+    R.plane = B.px.as<uint8_t>() + P.px_off;
+    R.status = B.status.as<int32_t>() + i;
+    R.wblk = P.wb; R.hblk = P.hb; R.pitch = qs_plane_pitch(P.wb);
+    R.mode = (comp_rebalance(job, P.ci, flags) ? QS_PLANE_REBALANCE : 0) |
+             (P.halo_top ? 0 : QS_PLANE_REP_TOP) | (P.halo_bot ? 0 : QS_PLANE_REP_BOT);
+  }
+  for (int i = np; i < QS_MAX_PLANES + 2; ++i) set.wave0[i] = w;
+  return QS_HIP_OK;
+}
+
+static const BandPlane* find_plane(const Band& B, int ci) {
+  for (const BandPlane& P : B.planes) if (P.ci == ci) return &P;
+  return nullptr;
+}
+
+// range-check flags of every band -> true when any plane tripped
+static int read_flags(Bands& bands, bool& bad) {
+  bad = false;
+  for (Band& B : bands.b) {
+    HIP_TRY(hipSetDevice(B.dev));
+    HIP_TRY(B.down.wait_first(B.s));
+    const int32_t* hst = static_cast<const int32_t*>(B.hstatus.p);
+    for (size_t i = 0; i < B.planes.size(); ++i) bad |= hst[i] != 0;
+  }
+  return QS_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// independent components: one plane set per band
+static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vector<int>& devices) {
+  const double t_start = wall_ms();
+  Bands bands(devices.size());
+  if (int r = open_bands(bands, devices)) return r;
+  const int n = (int)devices.size();
+
+  // every component is cut into min(n, hblk / 8) bands (a band keeps at least 8 block rows),
+  // which go to the first devices of the list
+  for (int ci = 0; ci < job->ncomp; ++ci) {
+    const int hb = job->hblk[ci];
+    const int nb = std::max(1, std::min(n, hb / 8));
+    for (int d = 0; d < nb; ++d) {
+      BandPlane P;
+      int r0, r1;
+      band_rows(hb, nb, d, r0, r1);
+      P.ci = ci; P.wb = job->wblk[ci]; P.hb = r1 - r0; P.r0 = r0;
+      P.halo_top = d > 0; P.halo_bot = d < nb - 1;
+      bands.b[d].planes.push_back(P);
+    }
+  }
+  for (Band& B : bands.b) {
+    HIP_TRY(hipSetDevice(B.dev));
+    if (int r = stage_band(B, job, flags)) return r;
+  }
+  const double t_up = wall_ms();
+
+  const int diag = (flags & QS_DIAGONALS) != 0;
+  for (int it = 0; it < niter; ++it) {
+    for (size_t d = 0; d < bands.b.size(); ++d) {
+      Band& B = bands.b[d];
+      HIP_TRY(hipSetDevice(B.dev));
+      if (int r = before_overwrite(bands, d)) return r;
+      qs_launch_idct_set(B.set, it == 0, B.s);
+    }
+    // one pixel row per component and band edge
+    if (int r = exchange(bands, job->ncomp, [&](int d, int ci, uint8_t** p, int* wb, int* hb) {
+          const BandPlane* P = find_plane(bands.b[d], ci);
+          if (!P) return false;
+          *p = bands.b[d].px.as<uint8_t>() + P->px_off; *wb = P->wb; *hb = P->hb;
+          return true;
+        })) return r;
+    for (Band& B : bands.b) {
+      HIP_TRY(hipSetDevice(B.dev));
+      qs_launch_smooth_set(B.set, diag, it == niter - 1, B.s);
+    }
+  }
+  for (Band& B : bands.b) {
+    HIP_TRY(hipSetDevice(B.dev));
+    HIP_TRY(hipGetLastError());
+    const size_t np = std::max<size_t>(1, B.planes.size());
+    if (!B.hstatus.alloc(np * sizeof(int32_t))) return qs_fail(QS_HIP_ENOMEM, "out of pinned host memory");
+    HIP_TRY(hipMemcpyAsync(B.hstatus.p, B.status.p, np * sizeof(int32_t), hipMemcpyDeviceToHost, B.s));
+    size_t coef_bytes = 0;
+    for (const BandPlane& P : B.planes) coef_bytes += P.cbytes;
+    HIP_TRY(B.down.issue(B.coef.p, coef_bytes, B.s));
+  }
+  const double t_enq = wall_ms();
+
+  bool bad = false;
+  if (int r = read_flags(bands, bad)) return r;
+  if (bad) return JOB_RERUN_CAREFUL;                          // host input is still untouched
+  for (Band& B : bands.b) {
+    HIP_TRY(hipSetDevice(B.dev));
+    std::vector<Piece> back;
+    for (const BandPlane& P : B.planes)
+      back.push_back({job->coef[P.ci] + (size_t)P.r0 * P.wb * 64, P.coef_off, P.cbytes});
+    HIP_TRY(B.down.finish(B.coef.p, back, B.s));
+  }
+  if (trace_on())
+    fprintf(stderr, "qs_hip trace: sharded(set) %d band(s)  upload+stage %.2f ms  enqueue %.2f ms  drain+scatter %.2f ms\n",
+            n, t_up - t_start, t_enq - t_up, wall_ms() - t_enq);
+  for (int ci = 0; ci < job->ncomp; ++ci)                    // reference :2851-2859
+    if (job->has_quant[ci]) for (int i = 0; i < 64; ++i) job->quant[ci][i] = 1;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// coupled YCbCr job (JOINT_YUV and/or UPSAMPLE_UV, optionally LOW_QUALITY): the order of
+// qs_job.cpp's general route, band by band.  aux[0] = L (luma at chroma resolution; the luma
+// plane itself when luma is 1x1), aux[1..2] = upsampled pixel buffers, aux[3..4] = upsampled
+// coefficient arrays.
+static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::vector<int>& devices) {
+  const double t_start = wall_ms();
+  const int ws = job->hsamp[0], hs = job->vsamp[0];
+  const int hby = job->hblk[0], hbc = job->hblk[1];
+  // bands are cut on chroma block rows; at least 8 of them per band
+  const int n = std::max(1, std::min((int)devices.size(), hbc / 8));
+  std::vector<int> devs(devices.begin(), devices.begin() + n);
+  Bands bands((size_t)n);
+  if (int r = open_bands(bands, devs)) return r;
+
+  const bool lowq = (flags & QS_LOW_QUALITY) != 0;
+  const bool sub = !(ws == 1 && hs == 1);                    // L is a separate, downsampled plane
+  const bool upsample = (flags & QS_UPSAMPLE_UV) && sub;     // reference :2805 (image1 only when subsampled)
+  const bool joint = (flags & QS_JOINT_YUV) != 0;
+  const int plane_flags = flags & (QS_DIAGONALS | QS_NO_REBALANCE | QS_NO_REBALANCE_UV);
+  const int diag = (plane_flags & QS_DIAGONALS) != 0;
+
+  for (int d = 0; d < n; ++d) {
+    Band& B = bands.b[d];
+    int c0, c1;
+    band_rows(hbc, n, d, c0, c1);
+    const int y0 = std::min(c0 * hs, hby), y1 = d == n - 1 ? hby : std::min(c1 * hs, hby);
+    for (int ci = 0; ci < 3; ++ci) {
+      BandPlane P;
+      P.ci = ci; P.wb = job->wblk[ci];
+      P.r0 = ci ? c0 : y0; P.hb = ci ? c1 - c0 : y1 - y0;
+      P.halo_top = d > 0; P.halo_bot = d < n - 1;
+      B.planes.push_back(P);
+    }
+    HIP_TRY(hipSetDevice(B.dev));
+    if (int r = stage_band(B, job, flags)) return r;
+    if (sub) HIP_TRY(B.aux[0].alloc(qs_hip_plane_bytes(job->wblk[1], c1 - c0)));
+  }
+  const double t_up = wall_ms();
+
+  auto plane_of = [&](int ci) {
+    return [&bands, ci](int d, int, uint8_t** p, int* wb, int* hb) {
+      const BandPlane& P = bands.b[d].planes[ci];
+      *p = bands.b[d].px.as<uint8_t>() + P.px_off; *wb = P.wb; *hb = P.hb;
+      return true;
+    };
+  };
+  auto ref = [](Band& B, int ci) -> QsPlaneRef& { return B.set.ref[ci]; };
+  auto lowres = [&](Band& B) -> uint8_t* { return sub ? B.aux[0].as<uint8_t>() : ref(B, 0).plane; };
+
+  // ---- luma: niter iterations + the refresh pass that feeds the chroma stages
+  for (int it = 0; it <= niter; ++it) {
+    for (size_t d = 0; d < bands.b.size(); ++d) {
+      Band& B = bands.b[d];
+      HIP_TRY(hipSetDevice(B.dev));
+      if (int r = before_overwrite(bands, d)) return r;
+      const BandPlane& P = B.planes[0];
+      qs_launch_idct_plane(ref(B, 0).cst, ref(B, 0).coef, ref(B, 0).plane, P.wb, P.hb, it == 0,
+                           !P.halo_top, !P.halo_bot, ref(B, 0).status, B.s);
+    }
+    const bool refresh = it == niter;
+    // the refresh pass of a subsampled luma only feeds the downsample, which stays inside the band
+    if (!refresh || !sub)
+      if (int r = exchange(bands, 1, plane_of(0))) return r;
+    if (refresh) break;
+    for (Band& B : bands.b) {
+      HIP_TRY(hipSetDevice(B.dev));
+      const BandPlane& P = B.planes[0];
+      if (lowq)
+        qs_launch_lowq(ref(B, 0).cst, ref(B, 0).coef, ref(B, 0).plane, P.wb, P.hb, comp_rebalance(job, 0, flags), 0,
+                       2.0f * sqrtf(0.5f), B.s);
+      else
+        qs_launch_smooth_plane(ref(B, 0).cst, ref(B, 0).coef, ref(B, 0).plane, P.wb, P.hb, diag,
+                               comp_rebalance(job, 0, flags), 0, 0, P.wb * P.hb, B.s);
+    }
+  }
+  // the +-1023 clamp comes after the refresh pass (reference :2668-2689 sits after the loop)
+  for (Band& B : bands.b) {
+    HIP_TRY(hipSetDevice(B.dev));
+    const BandPlane& P = B.planes[0];
+    qs_launch_clamp(ref(B, 0).coef, (size_t)P.wb * P.hb, B.s);
+    if (sub)
+      qs_launch_downsample(ref(B, 0).plane, P.wb, P.hb, B.aux[0].as<uint8_t>(), B.planes[1].wb, B.planes[1].hb, ws, hs, B.s);
+  }
+  if (sub)
+    if (int r = exchange(bands, 1, [&](int d, int, uint8_t** p, int* wb, int* hb) {
+          *p = bands.b[d].aux[0].as<uint8_t>(); *wb = bands.b[d].planes[1].wb; *hb = bands.b[d].planes[1].hb;
+          return true;
+        })) return r;
+
+  // ---- chroma
+  const int w1 = (job->image_width + ws - 1) / ws, h1_img = (job->image_height + hs - 1) / hs;
+  const size_t up_pitch = qs_hip_upsample_pitch(job->image_width, ws);
+  for (int ci = 1; ci <= 2; ++ci) {
+    const int extra = upsample ? 1 : 0;
+    for (int it = 0; it < niter + extra; ++it) {
+      for (size_t d = 0; d < bands.b.size(); ++d) {
+        Band& B = bands.b[d];
+        HIP_TRY(hipSetDevice(B.dev));
+        if (int r = before_overwrite(bands, d)) return r;
+        const BandPlane& P = B.planes[ci];
+        qs_launch_idct_plane(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, P.wb, P.hb, it == 0,
+                             !P.halo_top, !P.halo_bot, ref(B, ci).status, B.s);
+      }
+      if (int r = exchange(bands, 1, plane_of(ci))) return r;
+      if (it == niter) break;
+      const int last = (it == niter - 1) && !extra;
+      for (Band& B : bands.b) {
+        HIP_TRY(hipSetDevice(B.dev));
+        const BandPlane& P = B.planes[ci];
+        const int reb = comp_rebalance(job, ci, flags);
+        if (lowq) {
+          if (joint) qs_launch_joint(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, lowres(B), P.wb, P.hb, reb, last, B.s);
+          else qs_launch_lowq(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, P.wb, P.hb, reb, last, 2.0f * sqrtf(0.5f), B.s);
+        } else {
+          if (joint) qs_launch_joint(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, lowres(B), P.wb, P.hb, 0, 0, B.s);
+          qs_launch_smooth_plane(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, P.wb, P.hb, diag, reb, last,
+                                 0, P.wb * P.hb, B.s);
+        }
+      }
+    }
+    if (extra)                                               // as for luma: clamp after the refresh
+      for (Band& B : bands.b) {
+        HIP_TRY(hipSetDevice(B.dev));
+        qs_launch_clamp(ref(B, ci).coef, (size_t)B.planes[ci].wb * B.planes[ci].hb, B.s);
+      }
+    if (upsample)
+      for (Band& B : bands.b) {
+        HIP_TRY(hipSetDevice(B.dev));
+        const BandPlane &Y = B.planes[0], &C = B.planes[ci];
+        const int px0 = C.r0 * 8;                               // first low-res pixel row of the band (image coordinates)
+        const int h1 = std::max(0, std::min(h1_img - px0, C.hb * 8));
+        const int first_rows = std::max(0, std::min(8 - px0, h1));
+        HIP_TRY(B.aux[ci].alloc(up_pitch * ((size_t)Y.hb * 8 + 8 * hs) + 64));
+        HIP_TRY(B.aux[2 + ci].alloc((size_t)Y.wb * Y.hb * 128));
+        HIP_TRY(hipMemsetAsync(B.aux[ci].p, 0, up_pitch * ((size_t)Y.hb * 8 + 8 * hs) + 64, B.s));
+        qs_launch_upsample(ref(B, ci).plane, lowres(B), C.wb, ref(B, 0).plane, Y.wb, B.aux[ci].as<uint8_t>(), (int)up_pitch,
+                           Y.wb * 8, Y.hb * 8, w1, h1, first_rows, ws, hs, B.s);
+        qs_launch_fdct_plane(B.aux[ci].as<uint8_t>(), (int)up_pitch, B.aux[2 + ci].as<int16_t>(), Y.wb, Y.hb, B.s);
+      }
+  }
+
+  // ---- results into pinned memory behind the kernels
+  const size_t up_row = (size_t)job->wblk[0] * 128;
+  for (Band& B : bands.b) {
+    HIP_TRY(hipSetDevice(B.dev));
+    HIP_TRY(hipGetLastError());
+    if (!B.hstatus.alloc(3 * sizeof(int32_t))) return qs_fail(QS_HIP_ENOMEM, "out of pinned host memory");
+    HIP_TRY(hipMemcpyAsync(B.hstatus.p, B.status.p, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, B.s));
+    size_t coef_bytes = 0;
+    for (const BandPlane& P : B.planes) coef_bytes += P.cbytes;
+    HIP_TRY(B.down.issue(B.coef.p, coef_bytes, B.s));
+    if (upsample)
+      for (int j = 0; j < 2; ++j)
+        HIP_TRY(B.down_up[j].issue(B.aux[3 + j].p, (size_t)B.planes[0].hb * up_row, B.s));
+  }
+  const double t_enq = wall_ms();
+
+  bool bad = false;
+  if (int r = read_flags(bands, bad)) return r;
+  if (bad) return JOB_RERUN_CAREFUL;
+  int16_t* up_host[2] = {nullptr, nullptr};
+  if (upsample)
+    for (int j = 0; j < 2; ++j) {
+      up_host[j] = static_cast<int16_t*>(malloc((size_t)hby * up_row));
+      if (!up_host[j]) { free(up_host[0]); return qs_fail(QS_HIP_ENOMEM, "out of host memory"); }
+    }
+  struct UpFree { int16_t** p; bool keep; ~UpFree() { if (!keep) { free(p[0]); free(p[1]); } } } up_free{up_host, false};
+  for (Band& B : bands.b) {
+    HIP_TRY(hipSetDevice(B.dev));
+    std::vector<Piece> back;
+    for (const BandPlane& P : B.planes)
+      back.push_back({job->coef[P.ci] + (size_t)P.r0 * P.wb * 64, P.coef_off, P.cbytes});
+    HIP_TRY(B.down.finish(B.coef.p, back, B.s));
+    if (upsample)
+      for (int j = 0; j < 2; ++j) {
+        const BandPlane& Y = B.planes[0];
+        HIP_TRY(B.down_up[j].finish(B.aux[3 + j].p,
+                                    std::vector<Piece>{{up_host[j] + (size_t)Y.r0 * Y.wb * 64, 0, (size_t)Y.hb * up_row}}, B.s));
+      }
+  }
+  if (trace_on())
+    fprintf(stderr, "qs_hip trace: sharded(colour) %d band(s)  upload+stage %.2f ms  enqueue %.2f ms  drain+scatter %.2f ms\n",
+            n, t_up - t_start, t_enq - t_up, wall_ms() - t_enq);
+  if (upsample) {                                            // reference :2836-2849
+    job->coef_up[0] = up_host[0]; job->coef_up[1] = up_host[1]; up_free.keep = true;
+    job->up_wblk = job->wblk[0]; job->up_hblk = job->hblk[0];
+    job->out_hsamp0 = job->out_vsamp0 = 1;
+  }
+  for (int ci = 0; ci < job->ncomp; ++ci)                    // reference :2851-2859
+    if (job->has_quant[ci]) for (int i = 0; i < 64; ++i) job->quant[ci][i] = 1;
+  return 0;
+}
+
+// ---- configuration ---------------------------------------------------------
+std::mutex g_cfg_mu;
+bool g_cfg_set = false;                // qs_hip_set_devices was called
+std::vector<int> g_cfg_devices;
+
+static std::vector<int> parse_devices(const char* v) {
+  std::vector<int> out;
+  if (!v || !*v) return out;
+  const int visible = qs_hip_device_count();
+  if (!strcmp(v, "all")) { for (int i = 0; i < visible; ++i) out.push_back(i); return out; }
+  for (const char* p = v; *p;) {
+    char* end = nullptr;
+    const long d = strtol(p, &end, 10);
+    if (end == p) break;
+    out.push_back((int)d);
+    p = *end == ',' ? end + 1 : end;
+    if (*end && *end != ',') break;
+  }
+  return out;
+}
+
+// the coupled route handles exactly the YCbCr layouts the general route couples
+static bool colour_shardable(const qs_hip_job* job, int flags, int niter) {
+  // (niter 0 = "upsample only": left to the general route, which knows the reference's corner cases)
+  if (niter < 1 || !job_needs_lowres(job, flags)) return false;
+  for (int ci = 0; ci < 3; ++ci) {
+    if (!job->has_quant[ci]) return false;
+    int acc = 0;
+    for (int i = 0; i < 64; ++i) acc |= job->quant[ci][i];
+    if (acc <= 1 || acc >= 0x800) return false;            // iterations skipped / stop: the general path knows how
+  }
+  // chroma planes must cover the luma band rows exactly: hblk[0] <= hblk[1] * v_samp (always true for
+  // libjpeg's geometry) and both chroma components alike
+  return job->wblk[1] == job->wblk[2] && job->hblk[1] == job->hblk[2] &&
+         job->hblk[0] <= job->hblk[1] * job->vsamp[0] && job->hblk[0] > (job->hblk[1] - 1) * job->vsamp[0];
+}
+
+}  // namespace
+
+std::vector<int> qsj::shard_devices_for(const qs_hip_job* job, int flags, int niter) {
+  std::vector<int> devs;
+  {
+    std::lock_guard<std::mutex> lk(g_cfg_mu);
+    if (g_cfg_set) devs = g_cfg_devices;
+    else if (const char* v = getenv("QS_HIP_DEVICES")) devs = parse_devices(v);
+    else { const int n = qs_hip_device_count(); for (int i = 0; i < n; ++i) devs.push_back(i); }
+  }
+  if (devs.size() < 2) return {};
+  static const size_t min_blocks = env_size("QS_HIP_SHARD_MIN_BLOCKS", (size_t)512 << 10);
+  size_t blocks = 0;
+  for (int ci = 0; ci < job->ncomp; ++ci) blocks += (size_t)job->wblk[ci] * job->hblk[ci];
+  if (blocks < min_blocks) return {};
+  if (!(job_fusable(job, flags) || colour_shardable(job, flags, niter))) return {};
+  return devs;
+}
+
+int qsj::run_sharded(qs_hip_job* job, int flags, int niter, const std::vector<int>& devices) {
+  if (devices.empty()) return qs_fail(QS_HIP_EINVAL, "sharded job: empty device list");
+  if (devices.size() > 64) return qs_fail(QS_HIP_EINVAL, "sharded job: more than 64 bands");
+  // the caller's current device is put back on every path
+  struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{current_device()};
+  if (job_fusable(job, flags)) return run_sharded_set(job, flags, niter, devices);
+  if (colour_shardable(job, flags, niter)) return run_sharded_colour(job, flags, niter, devices);
+  return qs_fail(QS_HIP_ENOTSUP, "sharded job: this flag / table combination runs on one device");
+}
+
+extern "C" int qs_hip_set_devices(const int* devices, int n) {
+  if (n < 0 || (n > 0 && !devices)) return qs_fail(QS_HIP_EINVAL, "qs_hip_set_devices: bad argument");
+  const int visible = qs_hip_device_count();
+  for (int i = 0; i < n; ++i)
+    if (devices[i] < 0 || devices[i] >= visible) return qs_fail(QS_HIP_EINVAL, "qs_hip_set_devices: no HIP device %d", devices[i]);
+  std::lock_guard<std::mutex> lk(g_cfg_mu);
+  g_cfg_set = n > 0;
+  g_cfg_devices.assign(devices, devices + n);
+  return QS_HIP_OK;
+}

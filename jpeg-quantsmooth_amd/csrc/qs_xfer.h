@@ -1,5 +1,12 @@
 // qs_xfer.h -- pooled device / pinned buffers, streams, the helper-thread pool and the
-// staged host<->device transfers of the job layer.  Included by qs_job.cpp only.
+// staged host<->device transfers of the job layer (qs_job.cpp, qs_shard.cpp).
+//
+// Every pooled device buffer and stream set remembers the HIP device it was created on
+// and is only handed to a caller whose current device is that one: a host process may
+// drive several GPUs (hipSetDevice per thread, or the sharded job route which walks over
+// all of them from one thread).  Pinned staging memory is allocated portable, i.e. usable
+// for DMA by every device.  The pools are C++17 inline variables: one instance per
+// library, however many translation units include this header.
 #pragma once
 #include <new>
 #include <mutex>
@@ -16,15 +23,24 @@
 
 extern "C" void qs_hip_release_cache(void);
 
-namespace {
+namespace qsx {
 
+struct CacheEntry { void* p; size_t n; int dev; };
+inline std::mutex g_cache_mu;
+inline std::vector<CacheEntry> g_cache;            // free device blocks (all devices)
+inline const size_t kCacheMaxBytes = (size_t)6 << 30;   // per device
 
-struct CacheEntry { void* p; size_t n; };
-static std::mutex g_cache_mu;
-static std::vector<CacheEntry> g_cache;            // free device blocks
-static const size_t kCacheMaxBytes = (size_t)6 << 30;
+inline int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; } return d; }
+// scope guard: make `dev` current, put the caller's device back on exit
+struct DeviceScope {
+  int prev = -1;
+  explicit DeviceScope(int dev) { prev = current_device(); if (dev != prev) (void)hipSetDevice(dev); else prev = -1; }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
 
-static size_t round_size(size_t n) {               // size classes: powers of two from 64 KiB
+inline size_t round_size(size_t n) {               // size classes: powers of two from 64 KiB
   size_t c = (size_t)64 << 10;
   while (c < n) c <<= 1;
   return c;
@@ -33,6 +49,7 @@ static size_t round_size(size_t n) {               // size classes: powers of tw
 struct DevBuf {
   void* p = nullptr;
   size_t n = 0;
+  int dev = 0;                                     // device the block lives on
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
@@ -40,10 +57,13 @@ struct DevBuf {
   hipError_t alloc(size_t bytes) {
     release();
     const size_t want = round_size(bytes);
+    dev = current_device();                        // allocations belong to the caller's current device
     {
       std::lock_guard<std::mutex> lk(g_cache_mu);
       for (size_t i = 0; i < g_cache.size(); ++i)
-        if (g_cache[i].n == want) { p = g_cache[i].p; n = want; g_cache.erase(g_cache.begin() + i); return hipSuccess; }
+        if (g_cache[i].n == want && g_cache[i].dev == dev) {
+          p = g_cache[i].p; n = want; g_cache.erase(g_cache.begin() + i); return hipSuccess;
+        }
     }
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {                         // make room and retry once
@@ -56,13 +76,16 @@ struct DevBuf {
   }
   void release() {
     if (!p) return;
-    std::lock_guard<std::mutex> lk(g_cache_mu);
-    size_t held = 0;
-    for (auto& c : g_cache) held += c.n;
-    if (held + n <= kCacheMaxBytes) g_cache.push_back({p, n}); else (void)hipFree(p);
+    {
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      size_t held = 0;
+      for (auto& c : g_cache) if (c.dev == dev) held += c.n;
+      if (held + n <= kCacheMaxBytes) { g_cache.push_back({p, n, dev}); p = nullptr; n = 0; return; }
+    }
+    { DeviceScope on(dev); (void)hipFree(p); }
     p = nullptr; n = 0;
   }
-  void take(DevBuf& o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+  void take(DevBuf& o) { release(); p = o.p; n = o.n; dev = o.dev; o.p = nullptr; o.n = 0; }
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -80,7 +103,7 @@ struct PinnedBuf {
   PinnedBuf(const PinnedBuf&) = delete;
   PinnedBuf& operator=(const PinnedBuf&) = delete;
   ~PinnedBuf() { release(); }
-  static std::vector<CacheEntry>& pool() { static std::vector<CacheEntry> v; return v; }
+  static std::vector<CacheEntry>& pool() { static std::vector<CacheEntry> v; return v; }   // (inline function: one per library)
   bool alloc(size_t bytes) {
     const size_t want = round_size(bytes);
     {
@@ -89,7 +112,7 @@ struct PinnedBuf {
       for (size_t i = 0; i < v.size(); ++i)
         if (v[i].n == want) { p = v[i].p; n = want; v.erase(v.begin() + i); return true; }
     }
-    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+    if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
     n = want;
     return true;
   }
@@ -98,34 +121,54 @@ struct PinnedBuf {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     size_t held = 0;
     for (auto& c : pool()) held += c.n;
-    if (held + n <= ((size_t)2 << 30)) pool().push_back({p, n}); else (void)hipHostFree(p);
+    if (held + n <= ((size_t)2 << 30)) pool().push_back({p, n, -1}); else (void)hipHostFree(p);
     p = nullptr; n = 0;
   }
 };
 
 
-static const size_t kStageMin = (size_t)1 << 20, kStageChunk = (size_t)8 << 20;
-static const int kStageThreads = 4;   // parts per chunk
-static const int kPoolThreads = 8;    // helper threads (several transfers can be in flight)
+inline const size_t kStageMin = (size_t)1 << 20, kStageChunk = (size_t)8 << 20;
+inline const int kStageThreads = 4;   // parts per chunk
+inline const int kPoolThreads = 8;    // helper threads (several transfers can be in flight)
 
 // Persistent helper threads for the host halves of the transfers (copying between
 // caller memory and pinned staging).  Leaked on purpose: the threads sleep on the
 // condition variable until the process ends.
 class HostPool {
  public:
-  struct Task { std::function<void(int)> fn; int n = 0; std::atomic<int> next{0}, done{0}; };
+  // `ready` (optional) counts finished items per group of `per_group` consecutive items,
+  // for callers that consume the work group by group (upload_pieces: one DMA per chunk)
+  struct Task {
+    std::function<void(int)> fn;
+    int n = 0;
+    std::atomic<int> next{0};
+    int done = 0;                      // guarded by mu
+    std::vector<int> group_done;       // guarded by mu
+    int per_group = 1;
+    std::mutex mu;
+    std::condition_variable cv;        // signalled when a group or the whole task completes
+  };
   typedef std::shared_ptr<Task> Handle;
   static HostPool& get() { static HostPool* p = new HostPool(kPoolThreads); return *p; }
   // fn(i) for every i in [0, n) on the helper threads, in index order; returns at once
-  Handle submit(int n, std::function<void(int)> fn) {
+  Handle submit(int n, std::function<void(int)> fn, int per_group = 0) {
     auto t = std::make_shared<Task>();
     t->fn = std::move(fn); t->n = n;
+    if (per_group > 0) { t->per_group = per_group; t->group_done.assign((size_t)(n + per_group - 1) / per_group, 0); }
     { std::lock_guard<std::mutex> lk(mu_); q_.push_back(t); }
     cv_.notify_all();
     return t;
   }
+  // the waiters sleep on the task's condition variable (no spinning: a host core per
+  // in-flight call would otherwise be burned for the length of the transfer)
   static void wait(const Handle& t) {
-    while (t->done.load(std::memory_order_acquire) < t->n) std::this_thread::yield();
+    std::unique_lock<std::mutex> lk(t->mu);
+    t->cv.wait(lk, [&] { return t->done >= t->n; });
+  }
+  static void wait_group(const Handle& t, int g) {
+    std::unique_lock<std::mutex> lk(t->mu);
+    const int want = std::min(t->per_group, t->n - g * t->per_group);
+    t->cv.wait(lk, [&] { return t->group_done[(size_t)g] >= want; });
   }
 
  private:
@@ -145,7 +188,16 @@ class HostPool {
         const int i = t->next.fetch_add(1, std::memory_order_relaxed);
         if (i >= t->n) break;
         t->fn(i);
-        t->done.fetch_add(1, std::memory_order_release);
+        bool wake;
+        {
+          std::lock_guard<std::mutex> lk(t->mu);
+          wake = ++t->done >= t->n;
+          if (!t->group_done.empty()) {
+            const int g = i / t->per_group;
+            wake |= ++t->group_done[(size_t)g] >= std::min(t->per_group, t->n - g * t->per_group);
+          }
+        }
+        if (wake) t->cv.notify_all();
       }
     }
   }
@@ -159,7 +211,7 @@ class HostPool {
 struct Piece { void* host; size_t off, len; };
 
 // bytes [lo, hi) of the arena image <-> the pieces that overlap them
-static void copy_range(char* stage, const std::vector<Piece>& pieces, size_t lo, size_t hi, bool to_stage) {
+inline void copy_range(char* stage, const std::vector<Piece>& pieces, size_t lo, size_t hi, bool to_stage) {
   for (const Piece& pc : pieces) {
     const size_t a = std::max(lo, pc.off), e = std::min(hi, pc.off + pc.len);
     if (e <= a) continue;
@@ -168,7 +220,7 @@ static void copy_range(char* stage, const std::vector<Piece>& pieces, size_t lo,
   }
 }
 // item i of a transfer = part (i % kStageThreads) of chunk (i / kStageThreads)
-static void copy_item(char* stage, const std::vector<Piece>& pieces, size_t bytes, int i, bool to_stage) {
+inline void copy_item(char* stage, const std::vector<Piece>& pieces, size_t bytes, int i, bool to_stage) {
   const size_t c0 = (size_t)(i / kStageThreads) * kStageChunk, clen = std::min(kStageChunk, bytes - c0);
   const size_t part = (clen / kStageThreads + 63) & ~(size_t)63;
   const size_t o = std::min(clen, (size_t)(i % kStageThreads) * part), e = std::min(clen, o + part);
@@ -177,7 +229,7 @@ static void copy_item(char* stage, const std::vector<Piece>& pieces, size_t byte
 
 // host -> device: the helpers gather 8 MiB chunks into pinned memory; this thread
 // queues a chunk's DMA as soon as its parts are in, so DMA and gathering overlap
-static hipError_t upload_pieces(void* dst, const std::vector<Piece>& pieces, size_t bytes, hipStream_t s, PinnedBuf& stage) {
+inline hipError_t upload_pieces(void* dst, const std::vector<Piece>& pieces, size_t bytes, hipStream_t s, PinnedBuf& stage) {
   if (bytes < kStageMin || !stage.alloc(bytes)) {
     for (const Piece& pc : pieces) {
       hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + pc.off, pc.host, pc.len, hipMemcpyHostToDevice, s);
@@ -186,17 +238,13 @@ static hipError_t upload_pieces(void* dst, const std::vector<Piece>& pieces, siz
     return hipSuccess;
   }
   const int nchunks = (int)((bytes + kStageChunk - 1) / kStageChunk);
-  auto done = std::make_shared<std::vector<std::atomic<int>>>(nchunks);
-  for (auto& d : *done) d.store(0);
   char* stg = static_cast<char*>(stage.p);
   const std::vector<Piece>* pcs = &pieces;
-  HostPool::Handle h = HostPool::get().submit(nchunks * kStageThreads, [=](int i) {
-    copy_item(stg, *pcs, bytes, i, true);
-    (*done)[i / kStageThreads].fetch_add(1, std::memory_order_release);
-  });
+  HostPool::Handle h = HostPool::get().submit(nchunks * kStageThreads,
+      [=](int i) { copy_item(stg, *pcs, bytes, i, true); }, kStageThreads);
   hipError_t err = hipSuccess;
   for (int c = 0; c < nchunks; ++c) {
-    while ((*done)[c].load(std::memory_order_acquire) < kStageThreads) std::this_thread::yield();
+    HostPool::wait_group(h, c);
     const size_t c0 = (size_t)c * kStageChunk, clen = std::min(kStageChunk, bytes - c0);
     if (err == hipSuccess)
       err = hipMemcpyAsync(static_cast<char*>(dst) + c0, stg + c0, clen, hipMemcpyHostToDevice, s);
@@ -219,7 +267,11 @@ struct Download {
   Download() = default;
   Download(const Download&) = delete;
   Download& operator=(const Download&) = delete;
-  ~Download() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+  ~Download() { reset(); }
+  void reset() {                          // (the copies must have completed)
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    ev.clear(); stage.release(); bytes = 0; staged = false;
+  }
 
   hipError_t issue(const void* src, size_t nbytes, hipStream_t s) {
     bytes = nbytes;
@@ -267,36 +319,44 @@ struct Download {
 };
 
 // copy `bytes` from pageable `src` to device `dst` on `s`
-static hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t s, PinnedBuf& stage) {
+inline hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t s, PinnedBuf& stage) {
   return upload_pieces(dst, std::vector<Piece>{{const_cast<void*>(src), 0, bytes}}, bytes, s, stage);
 }
 
 struct Streams {
   hipStream_t s[3] = {nullptr, nullptr, nullptr};
   hipEvent_t luma_done = nullptr;
+  int dev = 0;                         // the device the streams belong to
   ~Streams() {
+    DeviceScope on(dev);
     for (auto& x : s) if (x) (void)hipStreamDestroy(x);
     if (luma_done) (void)hipEventDestroy(luma_done);
   }
 };
 
-static std::vector<Streams*> g_stream_pool;
+inline std::vector<Streams*> g_stream_pool;
 
-struct StreamLease {     // borrow a ready-made set of streams, give it back on scope exit
+struct StreamLease {     // borrow a ready-made set of streams of the CURRENT device, give it back on scope exit
   Streams* p = nullptr;
   StreamLease() {
+    const int dev = current_device();
     {
       std::lock_guard<std::mutex> lk(g_cache_mu);
-      if (!g_stream_pool.empty()) { p = g_stream_pool.back(); g_stream_pool.pop_back(); return; }
+      for (size_t i = 0; i < g_stream_pool.size(); ++i)
+        if (g_stream_pool[i]->dev == dev) { p = g_stream_pool[i]; g_stream_pool.erase(g_stream_pool.begin() + i); return; }
     }
     Streams* n = new (std::nothrow) Streams;
     if (!n) return;
+    n->dev = dev;
     bool ok = true;
     for (int i = 0; i < 3 && ok; ++i) ok = hipStreamCreateWithFlags(&n->s[i], hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&n->luma_done, hipEventDisableTiming) == hipSuccess;
     if (!ok) { delete n; return; }
     p = n;
   }
+  StreamLease(const StreamLease&) = delete;
+  StreamLease& operator=(const StreamLease&) = delete;
+  StreamLease(StreamLease&& o) noexcept : p(o.p) { o.p = nullptr; }
   ~StreamLease() {
     if (!p) return;
     for (auto& x : p->s) (void)hipStreamSynchronize(x);   // nothing of this job may outlive it
@@ -305,4 +365,11 @@ struct StreamLease {     // borrow a ready-made set of streams, give it back on 
   }
 };
 
-}  // namespace
+// error paths: nothing may be freed while the streams still run.  Declare it AFTER the
+// buffers it protects (locals are destroyed in reverse order).
+struct DrainGuard {
+  Streams* st;
+  ~DrainGuard() { if (st) for (auto& x : st->s) (void)hipStreamSynchronize(x); }
+};
+
+}  // namespace qsx

@@ -63,7 +63,7 @@ class Job(C.Structure):
 class PlaneRef(C.Structure):
     """qs_hip_plane_ref: one plane of a plane-set launch (device pointers)"""
     _fields_ = [("d_consts", C.c_void_p), ("d_coef", C.c_void_p), ("d_plane", C.c_void_p), ("d_status", C.c_void_p),
-                ("wblk", C.c_int32), ("hblk", C.c_int32), ("luma", C.c_int32), ("reserved", C.c_int32)]
+                ("wblk", C.c_int32), ("hblk", C.c_int32), ("luma", C.c_int32), ("band", C.c_int32)]
 
 
 MAX_PLANES = 56
@@ -73,6 +73,8 @@ PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
 ABI = {
     "qs_hip_do_quantsmooth": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int, C.c_int, PROGRESS_FN, C.c_void_p]),
     "qs_hip_do_quantsmooth_batch": (C.c_int, [C.POINTER(C.POINTER(Job)), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "qs_hip_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "qs_hip_do_quantsmooth_sharded": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "qs_hip_free": (None, [C.c_void_p]),
     "qs_hip_release_cache": (None, []),
     "qs_hip_device_count": (C.c_int, []),
@@ -226,14 +228,24 @@ class HipQS:
                     hsamp0=job.out_hsamp0, vsamp0=job.out_vsamp0)
 
     def do_quantsmooth(self, coefs, quants, flags, niter, *, hsamp=None, vsamp=None,
-                       colorspace=None, image_size=None, progprec=0, progress=None, threads=None):
+                       colorspace=None, image_size=None, progprec=0, progress=None, threads=None, devices=None):
         """Whole do_quantsmooth() on copies of the inputs; same calling convention
         and result dict as the test oracles (`threads` is accepted and ignored:
-        the GPU has no use for jpegqs_control_t.threads)."""
+        the GPU has no use for jpegqs_control_t.threads).  devices=[...]: cut the job
+        over these HIP devices (qs_hip_do_quantsmooth_sharded; an ordinal may repeat)."""
         job, work = self._make_job(coefs, quants, hsamp, vsamp, colorspace, image_size)
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            ret = self._check(self.lib.qs_hip_do_quantsmooth_sharded(C.byref(job), flags, niter, arr, len(devices)))
+            return self._job_result(job, work, quants, ret)
         cb = PROGRESS_FN(progress) if progress else C.cast(None, PROGRESS_FN)
         ret = self._check(self.lib.qs_hip_do_quantsmooth(C.byref(job), flags, niter, progprec, cb, None))
         return self._job_result(job, work, quants, ret)
+
+    def set_devices(self, devices):
+        """qs_hip_set_devices: the device list large jobs are spread over ([] = default)"""
+        arr = (C.c_int * max(1, len(devices)))(*devices)
+        self._check(self.lib.qs_hip_set_devices(arr, len(devices)))
 
     def do_quantsmooth_batch(self, jobs, flags, niter):
         """qs_hip_do_quantsmooth_batch: `jobs` = list of dicts with the keyword

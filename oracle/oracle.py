@@ -285,3 +285,45 @@ class Reference(_Lib):
         self._block(c.ctypes.data_as(C.POINTER(C.c_int16)), q.ctypes.data_as(C.POINTER(C.c_uint16)),
                     plane.ctypes.data + off, p2, stride, flags, luma)
         return c
+
+
+def verify_bands(oracle, coef_in, quant, flags, niter, got, rows=16, luma=True):
+    """Exact check of a LARGE single-component plane against the oracle without running
+    the oracle on all of it: `rows` block rows at the top, in the middle and at the bottom
+    (together they cover the image's top/bottom edges and, over their whole width, its
+    left/right edge columns).  A block's result after n iterations depends only on blocks
+    within n block rows of it, so the oracle runs on a crop with niter + 1 margin rows.
+
+    coef_in(r0, r1) / got(r0, r1) -> int16 [r1 - r0, wblk, 64] numpy arrays (input and
+    result rows); hblk = coef_in.hblk.  -> list of dict(where, row0, row1, bad_blocks)."""
+    hblk = coef_in.hblk
+    rows = min(rows, hblk)
+    m = niter + 1
+    spans = [("top", 0, rows)]
+    if hblk > 3 * rows:
+        mid = (hblk - rows) // 2
+        spans.append(("middle", mid, mid + rows))
+    if hblk > rows:
+        spans.append(("bottom", hblk - rows, hblk))
+    out = []
+    for name, a, b in spans:
+        lo, hi = max(0, a - m), min(hblk, b + m)
+        crop = np.ascontiguousarray(coef_in(lo, hi))
+        want = oracle.do_quantsmooth([crop], [quant], flags, niter, threads=0,
+                                     colorspace=1 if luma else 3)["coefs"][0][a - lo:b - lo]
+        have = np.asarray(got(a, b))
+        bad = int((have != want).any(axis=2).sum())
+        out.append(dict(where=name, row0=a, row1=b, bad_blocks=bad))
+    return out
+
+
+class RowSource:
+    """adapter for verify_bands: rows of a numpy array or of a torch tensor (device or host)"""
+
+    def __init__(self, arr):
+        self.arr = arr
+        self.hblk = int(arr.shape[0])
+
+    def __call__(self, r0, r1):
+        a = self.arr[r0:r1]
+        return a.cpu().numpy() if hasattr(a, "cpu") else np.asarray(a)

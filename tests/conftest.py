@@ -55,3 +55,9 @@ def gpu(hip):
     if hip.device_count() <= 0:
         pytest.fail("no HIP device visible although the test is marked gpu")
     return hip
+
+
+@pytest.fixture(scope="session")
+def big_plane(synth):
+    """BASELINE configs[2] input: 8192x8192 luma, JPEG quality 50 (about 9 s to build, shared)"""
+    return synth.synth_gray(8192, 8192, 50)

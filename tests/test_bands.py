@@ -200,3 +200,23 @@ def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
     assert d["verify_band_edges_ok"] is True and d["verify_ok"] is True
     if "nccl" in extra:
         assert "RCCL unavailable" in d["config"]["comm_note"] and "gloo" in d["config"]["sharding"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("quality,size", [(6, 512), (5, 384)])
+def test_bench_sharded_colour_two_processes_one_gpu(gpu, quality, size):
+    """BASELINE configs[4] shape through bench.py as the driver launches it for N = 2: one process
+    per rank, ColourBand + run_colour_band_dist order (halos of luma, low-res luma and chroma over
+    torch.distributed), real kernels, both ranks on ONE GPU with gloo and host-staged halo rows.
+    Every rank compares its whole band (upsampled chroma included) with the oracle's result."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device", "--quality", str(quality),
+           "--size", str(size), "--niter", "2", "--steps", "1", "--warmup", "1", "--batch", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "4:2:0" in d["config"]["workload"]
+    assert d["verify_band_edges_ok"] is True and d["verify_ok"] is True

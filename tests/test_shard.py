@@ -1,0 +1,102 @@
+"""One job spread over several (logical) GPUs inside the C ABI (csrc/qs_shard.cpp):
+qs_hip_do_quantsmooth_sharded / qs_hip_set_devices.  On the one-GPU test box every band
+lives on device 0 (`devices=[0, 0, ...]`): the band split, the halo pulls, their event
+ordering and the band-local colour stages are the code that runs on a multi-GPU node, only
+the copies are device-local.  Everything is compared bit for bit with the unsharded oracle."""
+import numpy as np
+import pytest
+
+from helpers import assert_same_result, inject_extreme_blocks, load_golden
+
+
+def test_shard_abi_argument_checks(hip):
+    """no GPU needed: the entry points exist and validate their arguments"""
+    import ctypes as C
+    assert hip.lib.qs_hip_set_devices(None, 3) == -2            # QS_HIP_EINVAL
+    assert hip.lib.qs_hip_set_devices(None, 0) == 0             # back to the default list
+    bogus = (C.c_int * 2)(0, 99)
+    assert hip.lib.qs_hip_set_devices(bogus, 2) == -2           # no such device
+    assert b"no HIP device" in hip.lib.qs_hip_last_error()
+    job, _ = hip._make_job([np.zeros((2, 2, 64), np.int16)], [np.full(64, 4, np.uint16)])
+    assert hip.lib.qs_hip_do_quantsmooth_sharded(C.byref(job), 0, 3, None, 0) == -2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbands", [2, 3, 5, 8])
+def test_sharded_gray_equals_unsharded(gpu, oracle, synth, nbands):
+    coef, quant = synth.synth_gray(264, 520, 50, seed=4)        # 65 x 33 blocks
+    for flags in (0, 1, 16):
+        want = oracle.do_quantsmooth([coef], [quant], flags, 3)
+        got = gpu.do_quantsmooth([coef], [quant], flags, 3, devices=[0] * nbands)
+        assert_same_result(got, want, f"gray {nbands} bands flags={flags}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,samp", [((256, 160), (2, 2)), ((333, 517), (2, 2)), ((321, 200), (1, 1)),
+                                       ((208, 328), (2, 1)), ((200, 264), (1, 2)), ((320, 264), (4, 1))])
+def test_sharded_colour_independent_components(gpu, oracle, synth, size, samp):
+    """--quality 3/4 on YCbCr: one plane set per band, every component cut on its own rows"""
+    w, h = size
+    j = synth.synth_ycc(w, h, samp[0], samp[1], quality=45, seed=9)
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(w, h))
+    for flags, niter in ((0, 3), (1, 2), (32, 2)):
+        want = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+        for nb in (2, 4):
+            got = gpu.do_quantsmooth(j["coefs"], j["quants"], flags, niter, devices=[0] * nb, **kw)
+            assert_same_result(got, want, f"{size} {samp} flags={flags} bands={nb}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,samp,nbands", [((256, 320), (2, 2), 2), ((333, 517), (2, 2), 3), ((321, 400), (2, 2), 4),
+                                               ((160, 200), (1, 1), 2), ((208, 264), (2, 1), 2), ((200, 520), (1, 2), 3)])
+def test_sharded_colour_coupled_flags(gpu, oracle, synth, size, samp, nbands):
+    """--quality 5/6 (JOINT_YUV / UPSAMPLE_UV, also with LOW_QUALITY): bands cut on chroma block
+    rows, halos of luma, low-res luma and chroma, band-local downsample / upsample / re-FDCT"""
+    w, h = size
+    # extreme blocks: coefficients beyond +-1023 before the final clamp (the refresh passes must see them unclamped)
+    j = inject_extreme_blocks(synth.synth_ycc(w, h, samp[0], samp[1], quality=40, seed=12))
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(w, h))
+    for flags, niter in ((7, 2), (3, 2), (7, 1), (7 | 32, 1), (15, 2), (5, 1), (11, 1), (6 | 16, 2)):
+        want = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+        got = gpu.do_quantsmooth(j["coefs"], j["quants"], flags, niter, devices=[0] * nbands, **kw)
+        assert_same_result(got, want, f"{size} {samp} flags={flags} niter={niter} bands={nbands}")
+
+
+@pytest.mark.gpu
+def test_sharded_range_check_and_unsupported(gpu, oracle, synth):
+    """a coefficient out of range in one band: the whole job is re-run in the careful order
+    (reference stop semantics); flag combinations without a sharded route say so"""
+    job, want = load_golden("gray64_badcoef_q3_n2")
+    got = gpu.do_quantsmooth(job["coefs"], job["quants"], job["flags"], job["niter"], devices=[0, 0], **job["kw"])
+    assert_same_result(got, want, "bad coefficient, 2 bands")
+    coef, quant = synth.synth_gray(64, 64, 50)
+    with pytest.raises(Exception) as e:
+        gpu.do_quantsmooth([coef], [quant], 8, 2, devices=[0, 0])      # LOW_QUALITY gray: one device only
+    assert getattr(e.value, "code", None) == -4
+
+
+@pytest.mark.gpu
+def test_sharded_route_taken_transparently(gpu):
+    """qs_hip_do_quantsmooth itself shards once several devices are configured and the job is
+    large enough: the committed fuzz corpus with QS_HIP_DEVICES=0,0,0 and the size threshold at 1
+    (every job that has a sharded route takes it, batches included)"""
+    from test_gpu_parity import _run_py
+    out = _run_py("import runpy, sys; sys.argv = ['fuzz_gpu.py', 'run', 'tests/golden/fuzz_s2.jsonl']; "
+                  "runpy.run_path('tools/fuzz_gpu.py', run_name='__main__')",
+                  {"QS_HIP_DEVICES": "0,0,0", "QS_HIP_SHARD_MIN_BLOCKS": "1", "QS_HIP_TRACE": "1"})
+    assert "400 trials, 959 jobs" in out and " 0 failures" in out
+
+
+@pytest.mark.gpu
+def test_sharded_8192_equals_unsharded_gpu_and_oracle_bands(gpu, oracle, big_plane):
+    """BASELINE configs[2]/[3] scale: an 8192x8192 luma plane over 8 bands equals the one-device
+    result everywhere, and both equal the oracle on 16 block rows at the top, middle and bottom"""
+    from oracle.oracle import RowSource, verify_bands
+    coef, quant = big_plane
+    for flags in (0, 1):
+        one = gpu.do_quantsmooth([coef], [quant], flags, 3)
+        many = gpu.do_quantsmooth([coef], [quant], flags, 3, devices=[0] * 8)
+        assert one["ret"] == many["ret"] == 0
+        assert np.array_equal(one["coefs"][0], many["coefs"][0]), f"flags={flags}: sharded != unsharded"
+        for v in verify_bands(oracle, RowSource(coef), quant, flags, 3, RowSource(many["coefs"][0])):
+            assert v["bad_blocks"] == 0, (flags, v)
