@@ -71,6 +71,14 @@ typedef int (*qs_hip_progress_fn)(void *userdata, int cur, int max);
  * Returns the reference's `stop` (0 done, 1 cancelled/rejected input) or <0. */
 int qs_hip_do_quantsmooth(qs_hip_job *job, int flags, int niter, int progprec,
 		qs_hip_progress_fn progress, void *userdata);
+/* The same job with every component's blocks given as separate ROWS: rows[ci][y] points at
+ * wblk[ci] consecutive blocks of block row y -- what libjpeg's access_virt_barray hands out
+ * (reference quantsmooth.h:2557-2560) -- and job->coef[ci] is ignored.  The rows are read and,
+ * on success, rewritten in place; the library's helper threads gather them into / scatter them
+ * from its pinned staging memory, so a libjpeg-facing caller needs no intermediate copy
+ * (csrc/jpegqs_shim.c).  Rows must not overlap. */
+int qs_hip_do_quantsmooth_rows(qs_hip_job *job, int16_t *const *const *rows, int flags, int niter,
+		int progprec, qs_hip_progress_fn progress, void *userdata);
 /* The same for many jobs in one call (one flags/niter setting for all).  Jobs whose
  * components are independent of each other (no JOINT_YUV / UPSAMPLE_UV coupling, no
  * LOW_QUALITY: CLI --quality 3 and 4) are processed TOGETHER: one pass-A and one

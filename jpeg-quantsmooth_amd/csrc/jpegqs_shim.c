@@ -34,6 +34,23 @@ EXTERN(void) jinit_d_main_controller JPP((j_decompress_ptr, boolean));
 EXTERN(void) jinit_inverse_dct JPP((j_decompress_ptr));
 EXTERN(void) jinit_upsampler JPP((j_decompress_ptr));
 EXTERN(void) jinit_color_deconverter JPP((j_decompress_ptr));
+#ifdef LIBJPEG_TURBO_VERSION
+/* leading part of libjpeg-turbo's private struct jpeg_decomp_master (jpegint.h), as far as the
+ * field patched below; layout per version as in reference quantsmooth.h:44-60.  Compiled only
+ * when the shim is built against libjpeg-turbo headers; this image has libjpeg 9d headers only,
+ * so the branch is untested here (stated in DESIGN.md). */
+struct qs_turbo_master {
+	void (*prepare_for_output_pass) (j_decompress_ptr);
+	void (*finish_output_pass) (j_decompress_ptr);
+	boolean is_dummy_pass;
+#if LIBJPEG_TURBO_VERSION_NUMBER >= 2001090
+	boolean lossless;
+#endif
+	JDIMENSION first_iMCU_col, last_iMCU_col;
+	JDIMENSION first_MCU_col[MAX_COMPONENTS];
+	JDIMENSION last_MCU_col[MAX_COMPONENTS];
+};
+#endif
 #endif
 
 /* Why the last do_quantsmooth() of this thread returned non-zero.  The reference's return value
@@ -45,16 +62,44 @@ EXTERN(void) jinit_color_deconverter JPP((j_decompress_ptr));
 static __thread int qs_backend_status = 0;
 int jpegqs_hip_backend_status(void) { return qs_backend_status; }
 
+/* The only memory this file holds across libjpeg calls that is not in libjpeg's own pool: the
+ * two replacement chroma arrays the GPU library malloc'ed (UPSAMPLE_UV), between its return and
+ * their copy into new virtual arrays.  Should a libjpeg error exit (longjmp) fall into that
+ * window, the pointers stay parked here and the next call on this thread releases them. */
+static __thread void *qs_parked[2] = { NULL, NULL };
+static void release_parked(void) {
+	int j;
+	for (j = 0; j < 2; j++) if (qs_parked[j]) { qs_hip_free(qs_parked[j]); qs_parked[j] = NULL; }
+}
+
 static double now_ms(void) {
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);
 	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
+static int cmp_ptr(const void *a, const void *b) {
+	const char *x = *(char *const *)a, *y = *(char *const *)b;
+	return x < y ? -1 : x > y;
+}
+
+/* all row pointers distinct and non-overlapping <=> every row has its own memory, i.e. the
+ * virtual array is memory-resident and the pointers stay valid across access calls */
+static int rows_are_resident(j_decompress_ptr srcinfo, int16_t **rows, JDIMENSION n, size_t rowbytes) {
+	JDIMENSION y;
+	char **tmp = (char**)(*srcinfo->mem->alloc_small)((j_common_ptr)srcinfo, JPOOL_IMAGE, (size_t)n * sizeof(char*));
+	memcpy(tmp, rows, (size_t)n * sizeof(char*));
+	qsort(tmp, n, sizeof(char*), cmp_ptr);
+	for (y = 1; y < n; y++)
+		if ((size_t)(tmp[y] - tmp[y - 1]) < rowbytes) return 0;
+	return 1;
+}
+
 int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpegqs_control_t *opts) {
 	qs_hip_job job;
+	int16_t **rows[QS_HIP_MAXC] = { NULL, NULL, NULL, NULL };
 	int ci, i, ret, flags = opts->flags;
-	int upsampled = 0;
+	int upsampled = 0, in_place = 1;
 	double t0 = 0;
 	jpeg_component_info *comp;
 	JDIMENSION blk_y;
@@ -81,23 +126,28 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 	if (flags & JPEGQS_INFO_TIME) t0 = now_ms();
 
 	qs_backend_status = 0;
+	release_parked();
 	if (srcinfo->num_components < 1 || srcinfo->num_components > QS_HIP_MAXC) {
 		logfmt("jpegqs-hip: unsupported component count %d\n", srcinfo->num_components);
 		qs_backend_status = QS_HIP_EINVAL;
 		return 1;
 	}
 
-	/* ---- gather: one contiguous JCOEF array per component.
-	 * access_virt_barray hands out one JBLOCKROW (allocated row width may
-	 * exceed width_in_blocks; only the first width_in_blocks blocks count,
-	 * reference quantsmooth.h:2557-2560, 2591-2594). */
+	/* ---- the job's view of the coefficients: one pointer per JBLOCKROW, straight into libjpeg's
+	 * virtual arrays.  access_virt_barray hands out one row at a time (allocated row width may
+	 * exceed width_in_blocks; only the first width_in_blocks blocks count, reference
+	 * quantsmooth.h:2557-2560, 2591-2594).  For memory-resident arrays (the normal case) the row
+	 * pointers stay valid and are all distinct, and the GPU library gathers from / scatters to them
+	 * with its helper threads -- no intermediate copy on this side.  Arrays that libjpeg swaps
+	 * through a backing store re-use one window: detected by coinciding pointers, then the rows
+	 * are copied (second path below).  All scratch memory here comes from libjpeg's JPOOL_IMAGE
+	 * pool, so an error exit (longjmp) out of a libjpeg call cannot leak it. */
 	memset(&job, 0, sizeof(job));
 	job.ncomp = srcinfo->num_components;
 	job.colorspace = (int)srcinfo->jpeg_color_space;
 	job.image_width = (int)srcinfo->image_width;
 	job.image_height = (int)srcinfo->image_height;
 	for (ci = 0; ci < job.ncomp; ci++) {
-		size_t rowbytes;
 		comp = srcinfo->comp_info + ci;
 		job.wblk[ci] = (int)comp->width_in_blocks;
 		job.hblk[ci] = (int)comp->height_in_blocks;
@@ -109,17 +159,31 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 		if (comp->width_in_blocks == 0 || comp->height_in_blocks == 0) {
 			logfmt("jpegqs-hip: empty component %d\n", ci);
 			qs_backend_status = QS_HIP_EINVAL;
-			goto fail_free;
+			return 1;
 		}
-		rowbytes = (size_t)comp->width_in_blocks * sizeof(JBLOCK);
-		job.coef[ci] = (int16_t*)malloc(rowbytes * comp->height_in_blocks);
-		if (!job.coef[ci]) { logfmt("jpegqs-hip: out of memory\n"); qs_backend_status = QS_HIP_ENOMEM; goto fail_free; }
+		rows[ci] = (int16_t**)(*srcinfo->mem->alloc_small)((j_common_ptr)srcinfo, JPOOL_IMAGE,
+				(size_t)comp->height_in_blocks * sizeof(int16_t*));
 		for (blk_y = 0; blk_y < comp->height_in_blocks; blk_y++) {
 			JBLOCKARRAY buf = (*srcinfo->mem->access_virt_barray)
-					((j_common_ptr)srcinfo, coef_arrays[ci], blk_y, 1, FALSE);
-			memcpy((char*)job.coef[ci] + rowbytes * blk_y, buf[0], rowbytes);
+					((j_common_ptr)srcinfo, coef_arrays[ci], blk_y, 1, TRUE);
+			rows[ci][blk_y] = (int16_t*)buf[0];
 		}
+		if (!rows_are_resident(srcinfo, rows[ci], comp->height_in_blocks,
+				(size_t)comp->width_in_blocks * sizeof(JBLOCK))) in_place = 0;
 	}
+	if (!in_place)
+		for (ci = 0; ci < job.ncomp; ci++) {              /* copy path: rows are only valid one at a time */
+			size_t rowbytes;
+			comp = srcinfo->comp_info + ci;
+			rowbytes = (size_t)comp->width_in_blocks * sizeof(JBLOCK);
+			job.coef[ci] = (int16_t*)(*srcinfo->mem->alloc_large)((j_common_ptr)srcinfo, JPOOL_IMAGE,
+					rowbytes * comp->height_in_blocks);
+			for (blk_y = 0; blk_y < comp->height_in_blocks; blk_y++) {
+				JBLOCKARRAY buf = (*srcinfo->mem->access_virt_barray)
+						((j_common_ptr)srcinfo, coef_arrays[ci], blk_y, 1, FALSE);
+				memcpy((char*)job.coef[ci] + rowbytes * blk_y, buf[0], rowbytes);
+			}
+		}
 
 	/* reference :2569-2572 prints this when it starts on a component's plane:
 	 * every component with a table whose values are not all <= 1, unless the
@@ -134,13 +198,17 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 			logfmt("component[%i] : size %ix%i\n", ci, job.wblk[ci], job.hblk[ci]);
 		}
 
-	ret = qs_hip_do_quantsmooth(&job, flags & JPEGQS_FLAGS_MASK, opts->niter, opts->progprec,
-			opts->progress, opts->userdata);
+	if (in_place)
+		ret = qs_hip_do_quantsmooth_rows(&job, (int16_t *const *const *)rows, flags & JPEGQS_FLAGS_MASK,
+				opts->niter, opts->progprec, opts->progress, opts->userdata);
+	else
+		ret = qs_hip_do_quantsmooth(&job, flags & JPEGQS_FLAGS_MASK, opts->niter, opts->progprec,
+				opts->progress, opts->userdata);
 	if (ret < 0) {
 		/* no CPU fallback by design: report and leave the image untouched */
 		logfmt("jpegqs-hip: %s\n", qs_hip_last_error());
 		qs_backend_status = ret;
-		goto fail_free;
+		return 1;
 	}
 
 	/* The job layer rewrites every table it was given to all-ones unless it took
@@ -152,24 +220,21 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 			if (job.has_quant[ci])
 				for (i = 0; i < DCTSIZE2; i++)
 					if (job.quant[ci][i] != srcinfo->comp_info[ci].quant_table->quantval[i]) { changed = 1; break; }
-		if (!changed) {
-			for (ci = 0; ci < job.ncomp; ci++) free(job.coef[ci]);
-			return ret;
-		}
+		if (!changed) return ret;
 	}
 
-	/* ---- scatter the processed blocks back */
-	for (ci = 0; ci < job.ncomp; ci++) {
-		size_t rowbytes;
-		comp = srcinfo->comp_info + ci;
-		rowbytes = (size_t)comp->width_in_blocks * sizeof(JBLOCK);
-		for (blk_y = 0; blk_y < comp->height_in_blocks; blk_y++) {
-			JBLOCKARRAY buf = (*srcinfo->mem->access_virt_barray)
-					((j_common_ptr)srcinfo, coef_arrays[ci], blk_y, 1, TRUE);
-			memcpy(buf[0], (char*)job.coef[ci] + rowbytes * blk_y, rowbytes);
+	/* ---- copy path only: scatter the processed blocks back (in place there is nothing to do) */
+	if (!in_place)
+		for (ci = 0; ci < job.ncomp; ci++) {
+			size_t rowbytes;
+			comp = srcinfo->comp_info + ci;
+			rowbytes = (size_t)comp->width_in_blocks * sizeof(JBLOCK);
+			for (blk_y = 0; blk_y < comp->height_in_blocks; blk_y++) {
+				JBLOCKARRAY buf = (*srcinfo->mem->access_virt_barray)
+						((j_common_ptr)srcinfo, coef_arrays[ci], blk_y, 1, TRUE);
+				memcpy(buf[0], (char*)job.coef[ci] + rowbytes * blk_y, rowbytes);
+			}
 		}
-		free(job.coef[ci]); job.coef[ci] = NULL;
-	}
 
 	/* ---- UPSAMPLE_UV replaced the chroma arrays: new virtual arrays at luma
 	 * size, sampling factors 1x1 (reference :2696-2703, 2836-2849) */
@@ -177,6 +242,7 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 		JDIMENSION uw = (JDIMENSION)job.up_wblk, uh = (JDIMENSION)job.up_hblk;
 		size_t rowbytes = (size_t)uw * sizeof(JBLOCK);
 		jvirt_barray_ptr up[2];
+		qs_parked[0] = job.coef_up[0]; qs_parked[1] = job.coef_up[1];
 		for (ci = 0; ci < 2; ci++)
 			up[ci] = (*srcinfo->mem->request_virt_barray)
 					((j_common_ptr)srcinfo, JPOOL_IMAGE, FALSE, uw, uh, 1);
@@ -187,7 +253,7 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 						((j_common_ptr)srcinfo, up[ci], blk_y, 1, TRUE);
 				memcpy(buf[0], (char*)job.coef_up[ci] + rowbytes * blk_y, rowbytes);
 			}
-			qs_hip_free(job.coef_up[ci]);
+			qs_hip_free(job.coef_up[ci]); qs_parked[ci] = NULL;
 			coef_arrays[ci + 1] = up[ci];
 			srcinfo->comp_info[ci + 1].width_in_blocks = uw;
 			srcinfo->comp_info[ci + 1].height_in_blocks = uh;
@@ -217,6 +283,13 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 	 * jpeg_read_scanlines() works (reference :2861-2876) */
 	if (!(flags & JPEGQS_TRANSCODE)) {
 		if (upsampled) {
+#ifdef LIBJPEG_TURBO_VERSION
+			/* libjpeg-turbo keeps per-component MCU column limits in its private master
+			 * record; the chroma components now have luma's geometry (reference :2864-2867) */
+			struct qs_turbo_master *master = (struct qs_turbo_master *)srcinfo->master;
+			master->last_MCU_col[1] = master->last_MCU_col[0];
+			master->last_MCU_col[2] = master->last_MCU_col[0];
+#endif
 			jinit_color_deconverter(srcinfo);
 			jinit_upsampler(srcinfo);
 			jinit_d_main_controller(srcinfo, FALSE);
@@ -228,10 +301,6 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 	(void)upsampled;
 #endif
 	return ret;
-
-fail_free:
-	for (ci = 0; ci < job.ncomp; ci++) free(job.coef[ci]);
-	return 1;
 }
 
 #ifndef TRANSCODE_ONLY

@@ -45,6 +45,27 @@ struct Comp {            // per-component device state (kept until the job ends)
 
 }  // namespace
 
+static thread_local int16_t* const* const* tl_rows = nullptr;
+qsj::RowScope::RowScope(int16_t* const* const* rows) { tl_rows = rows; }
+qsj::RowScope::~RowScope() { tl_rows = nullptr; }
+bool qsj::rows_active() { return tl_rows != nullptr; }
+
+void qsj::host_pieces(const qs_hip_job* job, int ci, int row0, int nrows, size_t arena_off, std::vector<Piece>& out) {
+  const size_t rowbytes = (size_t)job->wblk[ci] * 128;
+  if (nrows <= 0) return;
+  if (!tl_rows) {
+    out.push_back({job->coef[ci] + (size_t)row0 * job->wblk[ci] * 64, arena_off, (size_t)nrows * rowbytes});
+    return;
+  }
+  int16_t* const* rows = tl_rows[ci];
+  for (int y = 0; y < nrows;) {                              // runs of rows that are adjacent in memory
+    int e = y + 1;
+    while (e < nrows && reinterpret_cast<char*>(rows[row0 + e]) == reinterpret_cast<char*>(rows[row0 + e - 1]) + rowbytes) ++e;
+    out.push_back({rows[row0 + y], arena_off + (size_t)y * rowbytes, (size_t)(e - y) * rowbytes});
+    y = e;
+  }
+}
+
 double qsj::wall_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -112,7 +133,13 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
     HIP_TRY(C.status.alloc(sizeof(int32_t)));
     if (int r = qs_hip_consts_build(&hc[ci], job->quant[ci], flags)) return r;
     HIP_TRY(hipMemcpyAsync(C.cst.p, &hc[ci], sizeof(QsConsts), hipMemcpyHostToDevice, s));
-    { const double t0 = wall_ms(); HIP_TRY(upload(C.coef.p, job->coef[ci], cbytes, s, C.stage)); t_upload += wall_ms() - t0; }
+    {
+      const double t0 = wall_ms();
+      std::vector<Piece> src;
+      host_pieces(job, ci, 0, hb, 0, src);
+      HIP_TRY(upload_pieces(C.coef.p, src, cbytes, s, C.stage));
+      t_upload += wall_ms() - t0;
+    }
     HIP_TRY(hipMemsetAsync(C.status.p, 0, sizeof(int32_t), s));
 
     bool have_plane = false;
@@ -223,7 +250,7 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
       if (!C.hstatus.alloc(sizeof(int32_t))) return qs_fail(QS_HIP_ENOMEM, "out of pinned host memory");
       HIP_TRY(hipMemcpyAsync(C.hstatus.p, C.status.p, sizeof(int32_t), hipMemcpyDeviceToHost, C.stream));
     }
-    HIP_TRY(C.down.issue(C.coef.p, cbytes, C.stream));
+    HIP_TRY(C.down.issue(C.coef.p, cbytes, C.stream, rows_active()));
     if (C.have_up && !stop) HIP_TRY(C.down_up.issue(C.up.p, ubytes, C.stream));
   }
 
@@ -240,8 +267,9 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
   for (int ci = 0; ci < job->ncomp; ++ci) {
     Comp& C = comp[ci];
     if (!C.processed) continue;
-    const size_t cbytes = (size_t)job->wblk[ci] * job->hblk[ci] * 64 * sizeof(int16_t);
-    HIP_TRY(C.down.finish(C.coef.p, std::vector<Piece>{{job->coef[ci], 0, cbytes}}, C.stream));
+    std::vector<Piece> dst;
+    host_pieces(job, ci, 0, job->hblk[ci], 0, dst);
+    HIP_TRY(C.down.finish(C.coef.p, dst, C.stream));
     if (C.have_up && !stop)
       HIP_TRY(C.down_up.finish(C.up.p, std::vector<Piece>{{up_host[ci - 1], 0, ubytes}}, C.stream));
   }
@@ -414,7 +442,7 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
     HIP_TRY(hipMemcpyAsync(G.cst.p, G.hc.data(), qtabs.size() * sizeof(QsConsts), hipMemcpyHostToDevice, G.s));
     std::vector<Piece> pieces;
     for (const FPlane& P : G.planes)
-      pieces.push_back({jobs[P.job]->coef[P.ci] + (size_t)P.src_row0 * P.wb * 64, P.coef_off, P.cbytes});
+      host_pieces(jobs[P.job], P.ci, P.src_row0, P.hb, P.coef_off, pieces);
     G.coef_bytes = coef_bytes;
     HIP_TRY(upload_pieces(G.coef.p, pieces, coef_bytes, G.s, G.stage));
     HIP_TRY(hipMemsetAsync(G.status.p, 0, (size_t)np * sizeof(int32_t), G.s));
@@ -444,7 +472,7 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
     // pinned: a pageable destination would make this call wait for the whole stream
     if (!G.hstatus.alloc((size_t)np * sizeof(int32_t))) return qs_fail(QS_HIP_ENOMEM, "out of pinned host memory");
     HIP_TRY(hipMemcpyAsync(G.hstatus.p, G.status.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, G.s));
-    HIP_TRY(G.down.issue(G.coef.p, coef_bytes, G.s));       // to pinned memory, right behind the kernels
+    HIP_TRY(G.down.issue(G.coef.p, coef_bytes, G.s, rows_active()));       // to pinned memory, right behind the kernels
     // a band job is scattered band by band; without the staging copy of its input (pinned memory
     // exhausted) nothing could be restored should a later band trip the range check: hold it back
     if (!G.stage.p) for (int ji : G.jobs) if (split[ji]) defer[ji] = 1;
@@ -457,10 +485,8 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
   // already written are restored from the pinned upload staging, which still holds the
   // original input.  Without that staging copy the job's bands are held back until all of
   // them have been checked.
-  auto result_piece = [&](const FPlane& P) {
-    const size_t row = (size_t)P.wb * 128;
-    return Piece{jobs[P.job]->coef[P.ci] + (size_t)(P.src_row0 + P.keep0) * P.wb * 64,
-                 P.coef_off + P.keep0 * row, (size_t)(P.keep1 - P.keep0) * row};
+  auto result_pieces = [&](const FPlane& P, std::vector<Piece>& out) {   // the rows of P that are results (not halo)
+    host_pieces(jobs[P.job], P.ci, P.src_row0 + P.keep0, P.keep1 - P.keep0, P.coef_off + (size_t)P.keep0 * P.wb * 128, out);
   };
   std::vector<FGroup*> held;
   auto drain_group = [&](FGroup& G) -> int {
@@ -472,7 +498,7 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
     if (hold) { held.push_back(&G); return QS_HIP_OK; }
     std::vector<Piece> back;
     for (const FPlane& P : G.planes)
-      if (!bad_job[P.job]) { back.push_back(result_piece(P)); scattered[P.job] = 1; }
+      if (!bad_job[P.job]) { result_pieces(P, back); scattered[P.job] = 1; }
     HIP_TRY(G.down.finish(G.coef.p, back, G.s));
     // the group's stream work is complete: recycle its device arenas and download staging now, so
     // that memory in flight is bounded by the window below and not by the size of the batch.  The
@@ -500,7 +526,7 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
   }
   for (FGroup* G : held) {
     std::vector<Piece> back;
-    for (const FPlane& P : G->planes) if (!bad_job[P.job]) back.push_back(result_piece(P));
+    for (const FPlane& P : G->planes) if (!bad_job[P.job]) result_pieces(P, back);
     HIP_TRY(G->down.finish(G->coef.p, back, G->s));
   }
   std::vector<int> rerun;
@@ -511,8 +537,9 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
     for (FGroup& G : groups)                                 // put the original rows back
       for (const FPlane& P : G.planes)
         if (P.job == ji && G.stage.p) {
-          const Piece pc = result_piece(P);
-          memcpy(pc.host, static_cast<const char*>(G.stage.p) + pc.off, pc.len);
+          std::vector<Piece> pcs;
+          result_pieces(P, pcs);
+          for (const Piece& pc : pcs) memcpy(pc.host, static_cast<const char*>(G.stage.p) + pc.off, pc.len);
         }
   }
   if (trace_on())
@@ -554,7 +581,7 @@ static int prepare_job(qs_hip_job* job, int flags, int* niter) {
   if (!job || job->ncomp < 1 || job->ncomp > QS_HIP_MAXC)
     return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: bad job");
   for (int ci = 0; ci < job->ncomp; ++ci) {
-    if (!job->coef[ci] || job->wblk[ci] <= 0 || job->hblk[ci] <= 0)
+    if ((!tl_rows && !job->coef[ci]) || job->wblk[ci] <= 0 || job->hblk[ci] <= 0)
       return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: component %d has no data", ci);
     if (job->hsamp[ci] < 1 || job->hsamp[ci] > 4 || job->vsamp[ci] < 1 || job->vsamp[ci] > 4)   // JPEG: 1..4
       return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth: component %d has sampling factors %dx%d",
@@ -630,6 +657,25 @@ static int do_quantsmooth_batch_impl(qs_hip_job* const* jobs, int njobs, int fla
 extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int progprec,
                                      qs_hip_progress_fn progress, void* userdata) {
   try {
+    return do_quantsmooth_impl(job, flags, niter, progprec, progress, userdata);
+  } catch (const std::bad_alloc&) {
+    return qs_fail(QS_HIP_ENOMEM, "out of host memory");
+  } catch (...) {
+    return qs_fail(QS_HIP_ENODEV, "unexpected internal error");
+  }
+}
+
+extern "C" int qs_hip_do_quantsmooth_rows(qs_hip_job* job, int16_t* const* const* rows, int flags, int niter, int progprec,
+                                          qs_hip_progress_fn progress, void* userdata) {
+  try {
+    if (!job || !rows || job->ncomp < 1 || job->ncomp > QS_HIP_MAXC)
+      return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth_rows: bad job");
+    for (int ci = 0; ci < job->ncomp; ++ci) {
+      if (!rows[ci] || job->hblk[ci] <= 0) return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth_rows: component %d has no rows", ci);
+      for (int y = 0; y < job->hblk[ci]; ++y)
+        if (!rows[ci][y]) return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth_rows: component %d row %d is null", ci, y);
+    }
+    RowScope scope(rows);
     return do_quantsmooth_impl(job, flags, niter, progprec, progress, userdata);
   } catch (const std::bad_alloc&) {
     return qs_fail(QS_HIP_ENOMEM, "out of host memory");

@@ -20,6 +20,21 @@ bool job_needs_lowres(const qs_hip_job* job, int flags);
 // components independent of each other and ordinary quant tables: the plane-set routes apply
 bool job_fusable(const qs_hip_job* job, int flags);
 
+// Host side of a job's blocks.  Normally job->coef[ci] is one contiguous array; through
+// qs_hip_do_quantsmooth_rows the caller hands over one pointer per block row instead (libjpeg's
+// JBLOCKROWs), which the transfer helpers gather from / scatter to directly.  host_pieces appends
+// the pieces for block rows [row0, row0 + nrows) of component ci, placed at `arena_off` of a device
+// arena (adjacent rows are merged into one piece).  The row table is per calling thread and set
+// for the duration of one entry-point call (RowScope).
+void host_pieces(const qs_hip_job* job, int ci, int row0, int nrows, size_t arena_off, std::vector<qsx::Piece>& out);
+bool rows_active();    // the current call came through qs_hip_do_quantsmooth_rows
+struct RowScope {
+  explicit RowScope(int16_t* const* const* rows);
+  ~RowScope();
+  RowScope(const RowScope&) = delete;
+  RowScope& operator=(const RowScope&) = delete;
+};
+
 // general route on the current device (qs_job.cpp)
 int run_job(qs_hip_job* job, int flags, int niter, int progprec,
             qs_hip_progress_fn progress, void* userdata, bool eager);

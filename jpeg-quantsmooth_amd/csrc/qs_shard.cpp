@@ -205,7 +205,7 @@ static int stage_band(Band& B, const qs_hip_job* job, int flags) {
   if (int r = upload_consts(B, job, flags)) return r;
   std::vector<Piece> pieces;
   for (const BandPlane& P : B.planes)
-    pieces.push_back({job->coef[P.ci] + (size_t)P.r0 * P.wb * 64, P.coef_off, P.cbytes});
+    host_pieces(job, P.ci, P.r0, P.hb, P.coef_off, pieces);
   if (coef_bytes) HIP_TRY(upload_pieces(B.coef.p, pieces, coef_bytes, B.s, B.stage));
   HIP_TRY(hipMemsetAsync(B.status.p, 0, (size_t)std::max(np, 1) * sizeof(int32_t), B.s));
 
@@ -303,7 +303,7 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
     HIP_TRY(hipMemcpyAsync(B.hstatus.p, B.status.p, np * sizeof(int32_t), hipMemcpyDeviceToHost, B.s));
     size_t coef_bytes = 0;
     for (const BandPlane& P : B.planes) coef_bytes += P.cbytes;
-    HIP_TRY(B.down.issue(B.coef.p, coef_bytes, B.s));
+    HIP_TRY(B.down.issue(B.coef.p, coef_bytes, B.s, rows_active()));
   }
   const double t_enq = wall_ms();
 
@@ -314,7 +314,7 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
     HIP_TRY(hipSetDevice(B.dev));
     std::vector<Piece> back;
     for (const BandPlane& P : B.planes)
-      back.push_back({job->coef[P.ci] + (size_t)P.r0 * P.wb * 64, P.coef_off, P.cbytes});
+      host_pieces(job, P.ci, P.r0, P.hb, P.coef_off, back);
     HIP_TRY(B.down.finish(B.coef.p, back, B.s));
   }
   if (trace_on())
@@ -476,7 +476,7 @@ static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::
     HIP_TRY(hipMemcpyAsync(B.hstatus.p, B.status.p, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, B.s));
     size_t coef_bytes = 0;
     for (const BandPlane& P : B.planes) coef_bytes += P.cbytes;
-    HIP_TRY(B.down.issue(B.coef.p, coef_bytes, B.s));
+    HIP_TRY(B.down.issue(B.coef.p, coef_bytes, B.s, rows_active()));
     if (upsample)
       for (int j = 0; j < 2; ++j)
         HIP_TRY(B.down_up[j].issue(B.aux[3 + j].p, (size_t)B.planes[0].hb * up_row, B.s));
@@ -497,7 +497,7 @@ static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::
     HIP_TRY(hipSetDevice(B.dev));
     std::vector<Piece> back;
     for (const BandPlane& P : B.planes)
-      back.push_back({job->coef[P.ci] + (size_t)P.r0 * P.wb * 64, P.coef_off, P.cbytes});
+      host_pieces(job, P.ci, P.r0, P.hb, P.coef_off, back);
     HIP_TRY(B.down.finish(B.coef.p, back, B.s));
     if (upsample)
       for (int j = 0; j < 2; ++j) {
@@ -567,7 +567,7 @@ std::vector<int> qsj::shard_devices_for(const qs_hip_job* job, int flags, int ni
     else { const int n = qs_hip_device_count(); for (int i = 0; i < n; ++i) devs.push_back(i); }
   }
   if (devs.size() < 2) return {};
-  static const size_t min_blocks = env_size("QS_HIP_SHARD_MIN_BLOCKS", (size_t)512 << 10);
+  const size_t min_blocks = env_size("QS_HIP_SHARD_MIN_BLOCKS", (size_t)512 << 10);   // (read per call: tests lower it)
   size_t blocks = 0;
   for (int ci = 0; ci < job->ncomp; ++ci) blocks += (size_t)job->wblk[ci] * job->hblk[ci];
   if (blocks < min_blocks) return {};

@@ -230,7 +230,9 @@ inline void copy_item(char* stage, const std::vector<Piece>& pieces, size_t byte
 // host -> device: the helpers gather 8 MiB chunks into pinned memory; this thread
 // queues a chunk's DMA as soon as its parts are in, so DMA and gathering overlap
 inline hipError_t upload_pieces(void* dst, const std::vector<Piece>& pieces, size_t bytes, hipStream_t s, PinnedBuf& stage) {
-  if (bytes < kStageMin || !stage.alloc(bytes)) {
+  // small transfers go straight from the caller's memory -- unless they come in many pieces
+  // (a row table whose rows are not adjacent): then one staged DMA beats a copy call per row
+  if ((bytes < kStageMin && pieces.size() <= 4) || !stage.alloc(bytes)) {
     for (const Piece& pc : pieces) {
       hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + pc.off, pc.host, pc.len, hipMemcpyHostToDevice, s);
       if (e != hipSuccess) return e;
@@ -273,9 +275,10 @@ struct Download {
     ev.clear(); stage.release(); bytes = 0; staged = false;
   }
 
-  hipError_t issue(const void* src, size_t nbytes, hipStream_t s) {
+  // always_stage: the destination will be many separate pieces (see upload_pieces)
+  hipError_t issue(const void* src, size_t nbytes, hipStream_t s, bool always_stage = false) {
     bytes = nbytes;
-    staged = nbytes >= kStageMin && stage.alloc(nbytes);
+    staged = nbytes > 0 && (nbytes >= kStageMin || always_stage) && stage.alloc(nbytes);
     if (!staged) return hipSuccess;
     for (size_t c0 = 0; c0 < bytes; c0 += kStageChunk) {
       const size_t clen = std::min(kStageChunk, bytes - c0);

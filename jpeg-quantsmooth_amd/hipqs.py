@@ -73,6 +73,8 @@ PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
 ABI = {
     "qs_hip_do_quantsmooth": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int, C.c_int, PROGRESS_FN, C.c_void_p]),
     "qs_hip_do_quantsmooth_batch": (C.c_int, [C.POINTER(C.POINTER(Job)), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "qs_hip_do_quantsmooth_rows": (C.c_int, [C.POINTER(Job), C.POINTER(C.POINTER(C.c_void_p)), C.c_int, C.c_int, C.c_int,
+                                          PROGRESS_FN, C.c_void_p]),
     "qs_hip_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "qs_hip_do_quantsmooth_sharded": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "qs_hip_free": (None, [C.c_void_p]),

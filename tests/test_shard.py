@@ -100,3 +100,56 @@ def test_sharded_8192_equals_unsharded_gpu_and_oracle_bands(gpu, oracle, big_pla
         assert np.array_equal(one["coefs"][0], many["coefs"][0]), f"flags={flags}: sharded != unsharded"
         for v in verify_bands(oracle, RowSource(coef), quant, flags, 3, RowSource(many["coefs"][0])):
             assert v["bad_blocks"] == 0, (flags, v)
+
+
+def test_rows_entry_point_argument_checks(hip):
+    import ctypes as C
+    job, _ = hip._make_job([np.zeros((2, 2, 64), np.int16)], [np.full(64, 4, np.uint16)])
+    assert hip.lib.qs_hip_do_quantsmooth_rows(C.byref(job), None, 0, 3, 0, C.cast(None, hip.lib.qs_hip_do_quantsmooth_rows.argtypes[5]), None) == -2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("padded", [False, True])
+def test_job_given_as_rows_equals_contiguous(gpu, oracle, synth, padded):
+    """qs_hip_do_quantsmooth_rows: the blocks handed over as one pointer per block row (libjpeg's
+    JBLOCKROWs; `padded` = allocated rows wider than width_in_blocks, i.e. rows not adjacent) are
+    processed in place, for the fused, the general (coupled flags) and the sharded route"""
+    import ctypes as C
+    from jpeg_quantsmooth_amd.hipqs import PROGRESS_FN
+    j = synth.synth_ycc(200, 136, 2, 2, quality=45, seed=3)
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(200, 136))
+    for flags, devices in ((0, None), (1, None), (7, None), (11, None), (0, [0, 0]), (7, [0, 0])):
+        want = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, 2, **kw)
+        job, work = gpu._make_job(j["coefs"], j["quants"], j["hsamp"], j["vsamp"], 3, (200, 136))
+        store, tables = [], []
+        for ci, a in enumerate(work):
+            hb, wb = a.shape[:2]
+            pad = 3 if padded else 0
+            buf = np.zeros((hb, wb + pad, 64), np.int16)
+            buf[:, :wb] = a
+            store.append(buf)
+            tbl = (C.c_void_p * hb)(*[buf[y].ctypes.data for y in range(hb)])
+            tables.append(tbl)
+            job.coef[ci] = None
+        rows = (C.POINTER(C.c_void_p) * 4)(*[C.cast(t, C.POINTER(C.c_void_p)) for t in tables])
+        import os
+        if devices:                                              # transparent sharding: device list + size threshold
+            gpu.set_devices(devices)
+            os.environ["QS_HIP_SHARD_MIN_BLOCKS"] = "1"
+        try:
+            ret = gpu.lib.qs_hip_do_quantsmooth_rows(C.byref(job), rows, flags, 2, 0, C.cast(None, PROGRESS_FN), None)
+        finally:
+            gpu.set_devices([])
+            os.environ.pop("QS_HIP_SHARD_MIN_BLOCKS", None)
+        assert ret == want["ret"] == 0
+        for ci in range(3):
+            got = store[ci][:, :work[ci].shape[1]]
+            if want["up"] and ci:
+                cnt = job.up_wblk * job.up_hblk * 64
+                up = np.frombuffer((C.c_int16 * cnt).from_address(job.coef_up[ci - 1]), dtype=np.int16).reshape(job.up_hblk, job.up_wblk, 64)
+                assert np.array_equal(up, want["coefs"][ci]), (flags, ci)
+                gpu.lib.qs_hip_free(job.coef_up[ci - 1])
+            else:
+                assert np.array_equal(got, want["coefs"][ci]), (flags, ci, padded)
+            if padded:
+                assert not store[ci][:, work[ci].shape[1]:].any()      # nothing written beyond width_in_blocks
