@@ -38,6 +38,11 @@ struct QsConsts {
   int32_t tab_size;    // 160 or 272
   int32_t pad[15];
   float   tab[64 * QS_TAB_MAX]; // weight tables, row k = zigzag position
+  // Everything the recovery loop needs about zigzag position k in ONE 16-byte record, fetched
+  // with a single s_load_dwordx4 one coefficient ahead of its use:
+  //   [0] nat[k] | nat[max(k-1,1)] << 8 | x2[k] << 16    [1] q[k] (low 16, unsigned) | x1[k] << 16
+  //   [2] range[k] (float bits)                            [3] 0
+  int32_t rec[64][4];
 };
 
 static inline int qs_plane_pitch(int wblk) {

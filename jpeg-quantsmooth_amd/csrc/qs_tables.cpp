@@ -182,6 +182,13 @@ extern "C" int qs_hip_consts_build(void* host_out, const uint16_t quant[64], int
     c->nat[k] = i; c->q[k] = qn[i]; c->x1[k] = x1n[i]; c->x2[k] = x2n[i];
     c->range[k] = (float)(qn[i] * 2) * 0.000244140625f;  // R * 2^-12, see QS_TERM_D
   }
+  for (int k = 0; k < 64; ++k) {
+    const int kn = k > 1 ? k - 1 : 1;
+    c->rec[k][0] = c->nat[k] | (c->nat[kn] << 8) | (c->x2[k] << 16);
+    c->rec[k][1] = (int32_t)(((uint32_t)c->q[k] & 0xffffu) | ((uint32_t)c->x1[k] << 16));
+    memcpy(&c->rec[k][2], &c->range[k], sizeof(float));
+    c->rec[k][3] = 0;
+  }
   memcpy(c->tab, W.tab[diag], sizeof(c->tab));
   return QS_HIP_OK;
 }
