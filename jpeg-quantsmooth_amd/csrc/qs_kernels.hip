@@ -465,13 +465,21 @@ __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >
 #ifndef QS_FUSE_REBALANCE_SUMS
 #define QS_FUSE_REBALANCE_SUMS 1
 #endif
+// QS_EDGE_INLINE=1: no register-resident edge differences (see qs_smooth_kernel.inc): with
+// QS_SMOOTH_MIN_WAVES=4 the kernel fits 128 VGPRs = four waves per SIMD
+#ifndef QS_EDGE_INLINE
+#define QS_EDGE_INLINE 0
+#endif
+#ifndef QS_SMOOTH_OCCUPANCY       /* waves per SIMD the default kernel actually gets (tail-round rule) */
+#define QS_SMOOTH_OCCUPANCY 3
+#endif
 // tail-round wave priority (see qs_smooth_kernel.inc); workgroups the chip holds at
 // once = 256 CUs x 3 (the kernel's VGPR budget leaves room for 3 waves per SIMD and a
 // workgroup puts one wave on each of a CU's four SIMDs)
 #ifndef QS_TAIL_PRIO
 #define QS_TAIL_PRIO 1
 #endif
-#define QS_RESIDENT_WG (256 * 3 * 4 / QS_WAVES_PER_WG)
+#define QS_RESIDENT_WG (256 * QS_SMOOTH_OCCUPANCY * 4 / QS_WAVES_PER_WG)
 // measurement only: extra (unused) LDS dwords per wave, to cap how many workgroups a CU holds
 // without touching the code (occupancy experiments: 2400 -> 2 waves per SIMD), see DESIGN.md
 #ifndef QS_LDS_EXTRA
