@@ -435,23 +435,23 @@ typedef float qs_w16 __attribute__((ext_vector_type(16)));
                : "+s"(CUR), "=&s"(NXT), "+v"(num), "+v"(den) \
                : "s"(tabp), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)(BYTEOFF))) : "memory")
 
-// QS_REC_PREFETCH=1 (default): the per-coefficient scalars come from QsConsts::rec through an
-// explicit scalar load one coefficient ahead; 0 = left to the compiler (kept for A/B runs)
+// QS_REC_PREFETCH=1 (default): the per-coefficient scalars come from QsConsts::rec through ONE
+// explicit scalar load at the top of the coefficient; 0 = left to the compiler, which fetches them
+// with five global_load_dword + v_readfirstlane (kept for A/B runs)
 #ifndef QS_REC_PREFETCH
 #define QS_REC_PREFETCH 1
+#endif
+// QS_LAND_PIPELINE=1: chunk steps wait at their END for the load they issued at their start
+// (nothing in flight across statements other than one straight-line run of terms), and the
+// record of the next coefficient rides on the last step; 0 = wait at the start of the next step
+#ifndef QS_LAND_PIPELINE
+#define QS_LAND_PIPELINE 1
 #endif
 // per-coefficient record (QsConsts::rec), same discipline: issued right behind a weight-chunk
 // load, complete after the next s_waitcnt lgkmcnt(0)
 typedef int qs_i4 __attribute__((ext_vector_type(4)));
 #define QS_SLOAD4(BUF, BYTEOFF) \
   asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(BUF) : "s"(recp), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)(BYTEOFF))) : "memory")
-// QS_STEP plus the record of the NEXT coefficient (used by the first step of every coefficient)
-#define QS_STEP_R(CUR, NXT, BYTEOFF, RECBUF, RECOFF) \
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %[nxt], %[tp], %[to]\n\ts_load_dwordx4 %[rb], %[rp], %[ro]" \
-               : "+s"(CUR), [nxt] "=&s"(NXT), "+v"(num), "+v"(den), [rb] "=&s"(RECBUF) \
-               : [tp] "s"(tabp), [to] "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)(BYTEOFF))), \
-                 [rp] "s"(recp), [ro] "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)(RECOFF))) : "memory")
-
 __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >> (8 * n)) & 0xffu); }
 
 // waves per workgroup: the waves of a workgroup share nothing (each has its own
