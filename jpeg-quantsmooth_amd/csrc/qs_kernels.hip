@@ -27,6 +27,7 @@
 // QS_IDCT_DOT2, QS_ABLATE_*.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "qs_device.h"
 
 #define QS_LDS_PITCH 65 /* dwords per coefficient-pair row, 64 lanes + 1 pad */
@@ -543,6 +544,16 @@ __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >
 #undef QS_SMEM_PIPELINE
 #undef QS_SMOOTH_MIN_WAVES
 
+// Small planes: the diagonal-parallel form of the same pass (qs_smooth_dp_kernel.inc)
+#define QS_DP_KERNEL_NAME qs_smooth_dp_kernel
+#include "qs_smooth_dp_kernel.inc"
+#undef QS_DP_KERNEL_NAME
+#define QS_DP_KERNEL_NAME qs_smooth_dp_set_kernel
+#define QS_DP_SET 1
+#include "qs_smooth_dp_kernel.inc"
+#undef QS_DP_KERNEL_NAME
+#undef QS_DP_SET
+
 // --------------------------------------------------------------------------
 // Kernel C: stand-alone final clamp (used when the last smoothing launch did
 // not carry it: cancelled runs, refresh-only components).  8 coefs per lane.
@@ -596,10 +607,35 @@ void qs_launch_idct_plane(const QsConsts* cst, int16_t* coef, uint8_t* plane, in
                      cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), first, rep_top, rep_bot, status);
 }
 
+// Which form of pass B a launch of `groups` 64-block groups gets.  The diagonal-parallel kernel
+// (4 waves per 64 blocks: one per SIMD, so three workgroups fit a CU at the kernel's 3 waves per
+// SIMD) wins while all its workgroups are resident at once, i.e. up to 768 groups = 49 k blocks;
+// measured on MI355X (tools/bench_sizes.py, q3 / q4, us per launch): <= 256 groups 89 / 121 against
+// 198 / 293 for one block per lane, 512 groups 125 / 174 against 204 / 305, 768 groups 168 / 234
+// against 209 / 310, 1024 groups 224 / 309 against 218 / 327 -- beyond that the chip is busy anyway
+// and the one-block-per-lane kernel does 1.8x less work.  (6 waves per group were tried: a 6-wave
+// workgroup puts two waves on two of the four SIMDs, only ONE such workgroup fits a CU, and it is
+// no faster than 4 waves even below 256 groups.)  QS_HIP_DP=0 switches the small-plane kernel off
+// (A/B runs, tests of both forms); QS_HIP_DP_GROUPS moves the limit.
+#define QS_DP_WAVES 4
+static int qs_dp_waves(int groups) {
+  static const int on = [] { const char* v = getenv("QS_HIP_DP"); return v ? atoi(v) : 1; }();
+  static const int lim = [] { const char* v = getenv("QS_HIP_DP_GROUPS"); return v ? atoi(v) : 768; }();
+  return (on && groups <= lim) ? QS_DP_WAVES : 0;
+}
+
 void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* plane, int wblk, int hblk,
                             int diag, int rebalance, int final_clamp, int blk_begin, int blk_end, hipStream_t s) {
   const int n = blk_end - blk_begin;
   if (n <= 0) return;
+  if (const int nw = qs_dp_waves((n + 63) / 64)) {
+    const dim3 g((n + 63) / 64), b(64 * nw);
+    const int pitch_ = qs_plane_pitch(wblk);
+#define QS_GO_DP(D, W) hipLaunchKernelGGL((qs_smooth_dp_kernel<D, W>), g, b, 0, s, cst, coef, plane, wblk, hblk, pitch_, rebalance, final_clamp, blk_begin, blk_end)
+    if (diag) QS_GO_DP(true, QS_DP_WAVES); else QS_GO_DP(false, QS_DP_WAVES);
+#undef QS_GO_DP
+    return;
+  }
   const int per_wg = 64 * QS_WAVES_PER_WG;
   const dim3 grid((n + per_wg - 1) / per_wg), block(per_wg);
   // The pipelined kernel is the default at every size: measured A/B on MI355X it
@@ -627,6 +663,13 @@ void qs_launch_idct_set(const QsPlaneSet& set, int first, hipStream_t s) {
 void qs_launch_smooth_set(const QsPlaneSet& set, int diag, int final_clamp, hipStream_t s) {
   const int nw = set.wave0[set.n];
   if (nw <= 0) return;
+  if (const int dw = qs_dp_waves(nw)) {
+    const dim3 g(nw), b(64 * dw);
+#define QS_GO_DP(D, W) hipLaunchKernelGGL((qs_smooth_dp_set_kernel<D, W>), g, b, 0, s, set, final_clamp)
+    if (diag) QS_GO_DP(true, QS_DP_WAVES); else QS_GO_DP(false, QS_DP_WAVES);
+#undef QS_GO_DP
+    return;
+  }
   const dim3 grid((nw + QS_WAVES_PER_WG - 1) / QS_WAVES_PER_WG), block(64 * QS_WAVES_PER_WG);
   if (diag) hipLaunchKernelGGL(qs_smooth_set_kernel<true>, grid, block, 0, s, set, final_clamp);
   else      hipLaunchKernelGGL(qs_smooth_set_kernel<false>, grid, block, 0, s, set, final_clamp);

@@ -3,6 +3,7 @@
 hblk = 64 rows is one wave per SIMD on the whole chip.  Shows the latency floor
 (a lone wave), the occupancy steps and where the kernel reaches its streaming rate.
     python tools/bench_sizes.py [--flags 0] [--rows 64,128,...] [lib ...]"""
+import hashlib
 import sys
 from pathlib import Path
 
@@ -31,7 +32,7 @@ print("flags", flags, "rows:", rows)
 for lib in libs:
     hip = pkg.HipQS(lib)
     d_cst = torch.from_numpy(hip.consts_build(quant, flags)).to(dev)
-    out = []
+    out, hashes = [], []
     for hb in rows:
         src = full[:hb].contiguous()
         d_plane = torch.zeros(hip.plane_bytes(wb, hb), dtype=torch.uint8, device=dev)
@@ -46,5 +47,7 @@ for lib in libs:
             torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1))
         out.append(min(times[1:]))
+        hashes.append(hashlib.md5(c.cpu().numpy().tobytes()).hexdigest()[:6])
     print(f"{lib.name:36s} " + " ".join(f"{t * 1e3:7.0f}" for t in out) + "  us", flush=True)
+    print(f"{'  result md5':36s} " + " ".join(f"{h:>7s}" for h in hashes), flush=True)
     print(f"{'  Gblk-iter/s':36s} " + " ".join(f"{hb * wb / t / 1e6:7.3f}" for hb, t in zip(rows, out)), flush=True)
