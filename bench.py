@@ -279,7 +279,8 @@ def main():
                        "sharding": "none" if world == 1 else f"{world} block-row bands, 1-pixel-row halo over "
                                                                f"{'RCCL' if args.backend == 'nccl' else 'gloo (host-staged)'} per iteration, "
                                                                + ("exchange overlapped with the interior rows" if args.overlap
-                                                                  else "exchange between pass A and pass B in stream order"),
+                                                                  else "the planes of a step advance together: one batched exchange per "
+                                                                       "iteration between pass A and pass B, in stream order"),
                        "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
                        "blocks_per_gpu": res["blocks_per_gpu"], **({"comm_note": comm_note} if comm_note else {})},
             "roofline": {"bound": "hbm", "kernel": res["kernel"], "achieved": achieved_gbs,
@@ -362,6 +363,16 @@ def run_luma(c):
     is_band = topo.up is not None or topo.down is not None
     comm = eng.comm_scope() if (is_band and args.overlap) else None
     exch = bands.exchange_halo_dist if args.backend == "nccl" else bands.exchange_halo_dist_hostcopy
+    # sharded default: the planes of a step advance together, so that each iteration has ONE batched
+    # halo exchange for all of them (the exchange is latency-bound: 2 rows of 8 KB per plane)
+    engs = [eng] + [bands.HipBandEngine(hip, torch, work[0][b], quant, flags, luma=1, device=dev)
+                    for b in range(1, batch)] if (is_band and not args.overlap) else None
+    exch_many = bands.exchange_halo_dist_many if args.backend == "nccl" else bands.exchange_halo_dist_many_hostcopy
+
+    def one_step_sharded(planes):
+        for e, p in zip(engs, planes):
+            e.rebind(p)
+        bands.run_bands_batched(engs, topo, args.niter, lambda: exch_many(engs, topo, dist))
 
     def one_plane(coef, timed):
         eng.rebind(coef)
@@ -385,16 +396,22 @@ def run_luma(c):
                 ev_pairs.append((e0, e1))
 
     for i in range(args.warmup):
-        for p in work[i]:
-            one_plane(p, False)
+        if engs:
+            one_step_sharded(work[i])
+        else:
+            for p in work[i]:
+                one_plane(p, False)
     _fence(torch, dist, world)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        for bi, p in enumerate(work[args.warmup + i]):
-            one_plane(p, bi == 0)                        # HIP events around the first plane's launches of every step
+        if engs:
+            one_step_sharded(work[args.warmup + i])
+        else:
+            for bi, p in enumerate(work[args.warmup + i]):
+                one_plane(p, bi == 0)                    # HIP events around the first plane's launches of every step
     _fence(torch, dist, world)
     elapsed = _max_over_ranks(torch, dist, world, time.perf_counter() - t0, dev, args.backend)
-    assert not eng.bad_coef(), "range check tripped on synthetic input"
+    assert not any(e.bad_coef() for e in (engs or [eng])), "range check tripped on synthetic input"
     last = work[-1][-1]                                   # the last plane of the last timed step
 
     res = dict(elapsed=elapsed, batch=batch, total_blocks=total_blocks_plane * batch, blocks_per_gpu=hblk * wblk,

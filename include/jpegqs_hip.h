@@ -57,7 +57,8 @@ typedef struct {
 	uint16_t quant[QS_HIP_MAXC][64];   /* quantval[], natural order; set to 1 on return */
 	int16_t *coef[QS_HIP_MAXC];        /* hblk*wblk blocks of 64 JCOEF, in/out */
 	/* UPSAMPLE_UV only: replacement chroma arrays at luma resolution
-	 * (reference :2696-2703, 2836-2849); malloc'd, release with qs_hip_free() */
+	 * (reference :2696-2703, 2836-2849); owned by the caller, release with qs_hip_free()
+	 * (NOT free(): large arrays are pinned buffers of the library's pool) */
 	int16_t *coef_up[2];
 	int32_t up_wblk, up_hblk;          /* 0 when chroma was not replaced */
 	int32_t out_hsamp0, out_vsamp0;    /* component 0 sampling factors on return */

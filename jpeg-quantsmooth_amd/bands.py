@@ -110,6 +110,56 @@ def exchange_halo_dist_hostcopy(engine: BandEngine, topo: BandTopology, dist) ->
         engine.row(dst_y).copy_(buf)
 
 
+def exchange_halo_dist_many(engines, topo: BandTopology, dist) -> None:
+    """the halo rows of SEVERAL independent planes (a batch: one engine per plane, all cut into
+    the same bands) in ONE batched send/recv: the exchange is latency-bound (8 KB rows), so a
+    step over a batch of planes pays for it once per iteration instead of once per plane"""
+    ops = []
+    for engine in engines:
+        h = engine.hblk * 8
+        if topo.up is not None:
+            ops.append(dist.P2POp(dist.isend, engine.row(0), topo.up))
+            ops.append(dist.P2POp(dist.irecv, engine.row(-1), topo.up))
+        if topo.down is not None:
+            ops.append(dist.P2POp(dist.isend, engine.row(h - 1), topo.down))
+            ops.append(dist.P2POp(dist.irecv, engine.row(h), topo.down))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def exchange_halo_dist_many_hostcopy(engines, topo: BandTopology, dist) -> None:
+    """exchange_halo_dist_many staged through host memory (gloo: functional tests on one GPU)"""
+    import torch
+    ops, recvs = [], []
+    for engine in engines:
+        h = engine.hblk * 8
+        for nbr, src_y, dst_y in ((topo.up, 0, -1), (topo.down, h - 1, h)):
+            if nbr is None:
+                continue
+            out = engine.row(src_y).to("cpu")
+            buf = torch.empty_like(out)
+            ops.append(dist.P2POp(dist.isend, out, nbr))
+            ops.append(dist.P2POp(dist.irecv, buf, nbr))
+            recvs.append((engine, dst_y, buf))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for engine, dst_y, buf in recvs:
+        engine.row(dst_y).copy_(buf)
+
+
+def run_bands_batched(engines, topo: BandTopology, niter: int, exchange_many) -> None:
+    """one complete smoothing of the same band of several independent planes, iteration by
+    iteration for all of them: niter x {pass A of every plane, ONE halo exchange, pass B of every plane}"""
+    for it in range(niter):
+        for e in engines:
+            e.idct(it == 0, topo.rep_top, topo.rep_bot)
+        exchange_many()
+        for e in engines:
+            e.smooth(it == niter - 1)
+
+
 def exchange_halo_local(engines) -> None:
     """the same exchange between N logical bands living in one process
     (device-to-device copies): used to test the band logic on a single GPU"""

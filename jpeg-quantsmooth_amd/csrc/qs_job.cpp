@@ -101,7 +101,7 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
   DevBuf d_yfull, d_llow;          // full-res luma plane; luma at chroma resolution
   bool have_yfull = false, have_llow = false;
   int16_t* up_host[2] = { nullptr, nullptr };
-  struct UpFree { int16_t** p; bool keep; ~UpFree() { if (!keep) { free(p[0]); free(p[1]); } } } up_free{up_host, false};
+  struct UpFree { int16_t** p; bool keep; ~UpFree() { if (!keep) { qs_hip_free(p[0]); qs_hip_free(p[1]); } } } up_free{up_host, false};
   // declared after every buffer above: on any early return the streams are drained first,
   // only then do the buffers go back to the shared pools (another thread may take them at once)
   DrainGuard drain{lease.p};
@@ -214,8 +214,6 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
       const size_t ubytes = (size_t)uwb * uhb * 64 * sizeof(int16_t);
       HIP_TRY(C.px.alloc(qs_hip_upsample_bytes(job->image_width, job->image_height, ws, hs)));
       HIP_TRY(C.up.alloc(ubytes));
-      up_host[ci - 1] = static_cast<int16_t*>(malloc(ubytes));
-      if (!up_host[ci - 1]) return qs_fail(QS_HIP_ENOMEM, "out of host memory");
       if (int r = qs_hip_upsample_plane(C.plane.as<uint8_t>(), d_llow.as<uint8_t>(), wb, d_yfull.as<uint8_t>(),
                                         uwb, uhb, C.px.as<uint8_t>(), job->image_width, job->image_height,
                                         ws, hs, s)) return r;
@@ -270,8 +268,18 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
     std::vector<Piece> dst;
     host_pieces(job, ci, 0, job->hblk[ci], 0, dst);
     HIP_TRY(C.down.finish(C.coef.p, dst, C.stream));
-    if (C.have_up && !stop)
-      HIP_TRY(C.down_up.finish(C.up.p, std::vector<Piece>{{up_host[ci - 1], 0, ubytes}}, C.stream));
+    if (C.have_up && !stop) {
+      if (C.down_up.staged) {
+        // the replacement array IS the pinned download buffer: it changes owner (qs_hip_free gives it
+        // back to the pool) instead of being copied into fresh, page-faulting malloc memory
+        HIP_TRY(C.down_up.finish(C.up.p, std::vector<Piece>{}, C.stream));     // (waits for its chunks)
+        up_host[ci - 1] = static_cast<int16_t*>(pinned_handout(C.down_up.stage));
+      } else {
+        up_host[ci - 1] = static_cast<int16_t*>(malloc(ubytes));
+        if (!up_host[ci - 1]) return qs_fail(QS_HIP_ENOMEM, "out of host memory");
+        HIP_TRY(C.down_up.finish(C.up.p, std::vector<Piece>{{up_host[ci - 1], 0, ubytes}}, C.stream));
+      }
+    }
   }
   if (trace_on())
     fprintf(stderr, "qs_hip trace: %s  enqueue %.2f ms (host->pinned->device issue %.2f)  drain %.2f ms  scatter %.2f ms\n",

@@ -8,7 +8,7 @@
 #include <math.h>
 #include <mutex>
 
-#include "qs_common.h"
+#include "qs_xfer.h"
 
 // ---------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -37,7 +37,7 @@ extern "C" size_t qs_hip_plane_bytes(int wblk, int hblk) {
 extern "C" size_t qs_hip_plane_row_offset(int wblk, int y) {
   return (size_t)qs_plane_pitch(wblk) * (size_t)(y + 1);
 }
-extern "C" void qs_hip_free(void* p) { free(p); }
+extern "C" void qs_hip_free(void* p) { if (p && !qsx::pinned_return(p)) free(p); }
 
 // ---------------------------------------------------------------------------
 // constants

@@ -127,6 +127,31 @@ struct PinnedBuf {
 };
 
 
+// Pinned blocks handed to the caller as result arrays (qs_hip_job::coef_up): the download staging
+// buffer itself changes owner instead of being copied into freshly malloc'ed (page-faulting)
+// memory; qs_hip_free() recognises such a block and puts it back into the pinned pool.
+inline std::vector<CacheEntry>& pinned_handouts() { static std::vector<CacheEntry> v; return v; }
+inline void* pinned_handout(PinnedBuf& b) {
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  pinned_handouts().push_back({b.p, b.n, -1});
+  void* p = b.p;
+  b.p = nullptr; b.n = 0;
+  return p;
+}
+inline bool pinned_return(void* p) {
+  PinnedBuf b;
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    auto& v = pinned_handouts();
+    size_t i = 0;
+    while (i < v.size() && v[i].p != p) ++i;
+    if (i == v.size()) return false;
+    b.p = v[i].p; b.n = v[i].n;
+    v.erase(v.begin() + i);
+  }
+  return true;                                     // (b's destructor returns the block to the pool)
+}
+
 inline const size_t kStageMin = (size_t)1 << 20, kStageChunk = (size_t)8 << 20;
 inline const int kStageThreads = 4;   // parts per chunk
 inline const int kPoolThreads = 8;    // helper threads (several transfers can be in flight)

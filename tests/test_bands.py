@@ -67,6 +67,44 @@ def test_bands_gloo_equal_unsharded(world, overlapped, flags, oracle, synth, tmp
     assert np.array_equal(got, want)
 
 
+def _batched_worker(rank, world, port, tmp):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    import torch
+    import torch.distributed as dist
+    import jpegqs_pkg
+    from oracle.oracle import Oracle
+    from band_cpu_engine import OracleBandEngine
+    pkg = jpegqs_pkg.load()
+    from jpeg_quantsmooth_amd import bands
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    engs = []
+    for seed in (21, 22, 23):                                    # three independent planes = one batch
+        coef, quant = pkg.synth.synth_gray(136, 200, 45, seed=seed)
+        r0, r1 = bands.band_rows(coef.shape[0], world, rank)
+        engs.append(OracleBandEngine(Oracle(), pkg.HipQS(), coef[r0:r1].copy(), quant, 1))
+    topo = bands.BandTopology(rank, world, r0, r1)
+    bands.run_bands_batched(engs, topo, 3, lambda: bands.exchange_halo_dist_many(engs, topo, dist))
+    for n, e in enumerate(engs):
+        np.save(os.path.join(tmp, f"plane{n}_band{rank}.npy"), e.coef)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batched_bands_gloo_equal_unsharded(oracle, synth, tmp_path):
+    """the schedule bench.py uses for N > 1: the planes of a batch advance together, ONE batched
+    halo exchange per iteration for all of them (world_size 3, gloo, CPU engine)"""
+    import torch.multiprocessing as mp
+    world = 3
+    mp.spawn(_batched_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for n, seed in enumerate((21, 22, 23)):
+        coef, quant = synth.synth_gray(136, 200, 45, seed=seed)
+        want = oracle.do_quantsmooth([coef], [quant], 1, 3)["coefs"][0]
+        got = np.concatenate([np.load(tmp_path / f"plane{n}_band{r}.npy") for r in range(world)], axis=0)
+        assert np.array_equal(got, want), f"plane {n}"
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("nbands", [2, 5])
 def test_bands_on_one_gpu_equal_unsharded(gpu, pkg, oracle, synth, nbands):
