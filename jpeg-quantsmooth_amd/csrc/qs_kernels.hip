@@ -615,13 +615,18 @@ void qs_launch_idct_plane(const QsConsts* cst, int16_t* coef, uint8_t* plane, in
 // against 209 / 310, 1024 groups 224 / 309 against 218 / 327 -- beyond that the chip is busy anyway
 // and the one-block-per-lane kernel does 1.8x less work.  (6 waves per group were tried: a 6-wave
 // workgroup puts two waves on two of the four SIMDs, only ONE such workgroup fits a CU, and it is
-// no faster than 4 waves even below 256 groups.)  QS_HIP_DP=0 switches the small-plane kernel off
-// (A/B runs, tests of both forms); QS_HIP_DP_GROUPS moves the limit.
+// no faster than 4 waves even below 256 groups.)  Between 768 and 1024 groups the same kernel with
+// TWO waves per group (128 VGPRs, 4 waves per SIMD: all 2048 waves resident) is the fastest form:
+// 176 / 256 us at 1024 groups; at 1536 groups and beyond one block per lane wins (256 vs 286 us).
+// QS_HIP_DP=0 switches the small-plane kernel off (A/B runs, tests of both forms);
+// QS_HIP_DP_GROUPS / QS_HIP_DP_GROUPS2 move the two limits.
 #define QS_DP_WAVES 4
 static int qs_dp_waves(int groups) {
   static const int on = [] { const char* v = getenv("QS_HIP_DP"); return v ? atoi(v) : 1; }();
   static const int lim = [] { const char* v = getenv("QS_HIP_DP_GROUPS"); return v ? atoi(v) : 768; }();
-  return (on && groups <= lim) ? QS_DP_WAVES : 0;
+  static const int lim2 = [] { const char* v = getenv("QS_HIP_DP_GROUPS2"); return v ? atoi(v) : 1024; }();
+  if (!on) return 0;
+  return groups <= lim ? QS_DP_WAVES : groups <= lim2 ? 2 : 0;
 }
 
 void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* plane, int wblk, int hblk,
@@ -632,7 +637,8 @@ void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* p
     const dim3 g((n + 63) / 64), b(64 * nw);
     const int pitch_ = qs_plane_pitch(wblk);
 #define QS_GO_DP(D, W) hipLaunchKernelGGL((qs_smooth_dp_kernel<D, W>), g, b, 0, s, cst, coef, plane, wblk, hblk, pitch_, rebalance, final_clamp, blk_begin, blk_end)
-    if (diag) QS_GO_DP(true, QS_DP_WAVES); else QS_GO_DP(false, QS_DP_WAVES);
+    if (nw == 2) { if (diag) QS_GO_DP(true, 2); else QS_GO_DP(false, 2); }
+    else if (diag) QS_GO_DP(true, QS_DP_WAVES); else QS_GO_DP(false, QS_DP_WAVES);
 #undef QS_GO_DP
     return;
   }

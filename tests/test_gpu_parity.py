@@ -510,11 +510,12 @@ def test_gpu_vs_other_reference_orderings_information(gpu, oracle, synth):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"QS_HIP_DP": "0"}, {"QS_HIP_DP_GROUPS": "100000"}],
-                         ids=["one-block-per-lane", "diagonal-parallel"])
+@pytest.mark.parametrize("env", [{"QS_HIP_DP": "0"}, {"QS_HIP_DP_GROUPS": "100000"},
+                                 {"QS_HIP_DP_GROUPS": "0", "QS_HIP_DP_GROUPS2": "100000"}],
+                         ids=["one-block-per-lane", "diagonal-parallel-4-waves", "diagonal-parallel-2-waves"])
 def test_gpu_fuzz_corpus_every_pass_b_form(env):
     """Pass B exists in two forms -- one block per lane (large planes) and the diagonal-parallel
-    kernel with 4 waves per 64 blocks (small planes); the launcher picks by size, so the
+    kernel with 4 or 2 waves per 64 blocks (small planes); the launcher picks by size, so the
     default corpus run mostly sees the small-plane form.  Here each form is forced on EVERY plane of
     the committed corpus (all flags, layouts, sizes up to 1400x1050, batches): 0 mismatches each."""
     out = _run_py("import runpy, sys; sys.argv = ['fuzz_gpu.py', 'run', 'tests/golden/fuzz_s2.jsonl']; "
