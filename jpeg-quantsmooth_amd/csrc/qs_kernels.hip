@@ -672,7 +672,8 @@ void qs_launch_smooth_set(const QsPlaneSet& set, int diag, int final_clamp, hipS
   if (const int dw = qs_dp_waves(nw)) {
     const dim3 g(nw), b(64 * dw);
 #define QS_GO_DP(D, W) hipLaunchKernelGGL((qs_smooth_dp_set_kernel<D, W>), g, b, 0, s, set, final_clamp)
-    if (diag) QS_GO_DP(true, QS_DP_WAVES); else QS_GO_DP(false, QS_DP_WAVES);
+    if (dw == 2) { if (diag) QS_GO_DP(true, 2); else QS_GO_DP(false, 2); }
+    else if (diag) QS_GO_DP(true, QS_DP_WAVES); else QS_GO_DP(false, QS_DP_WAVES);
 #undef QS_GO_DP
     return;
   }
