@@ -545,6 +545,9 @@ __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >
 #undef QS_SMOOTH_MIN_WAVES
 
 // Small planes: the diagonal-parallel form of the same pass (qs_smooth_dp_kernel.inc)
+#ifndef QS_DP_SHARED_REFRESH
+#define QS_DP_SHARED_REFRESH 1
+#endif
 #define QS_DP_KERNEL_NAME qs_smooth_dp_kernel
 #include "qs_smooth_dp_kernel.inc"
 #undef QS_DP_KERNEL_NAME
@@ -607,24 +610,27 @@ void qs_launch_idct_plane(const QsConsts* cst, int16_t* coef, uint8_t* plane, in
                      cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), first, rep_top, rep_bot, status);
 }
 
-// Which form of pass B a launch of `groups` 64-block groups gets.  The diagonal-parallel kernel
-// (4 waves per 64 blocks: one per SIMD, so three workgroups fit a CU at the kernel's 3 waves per
-// SIMD) wins while all its workgroups are resident at once, i.e. up to 768 groups = 49 k blocks;
-// measured on MI355X (tools/bench_sizes.py, q3 / q4, us per launch): <= 256 groups 89 / 121 against
-// 198 / 293 for one block per lane, 512 groups 125 / 174 against 204 / 305, 768 groups 168 / 234
-// against 209 / 310, 1024 groups 224 / 309 against 218 / 327 -- beyond that the chip is busy anyway
-// and the one-block-per-lane kernel does 1.8x less work.  (6 waves per group were tried: a 6-wave
-// workgroup puts two waves on two of the four SIMDs, only ONE such workgroup fits a CU, and it is
-// no faster than 4 waves even below 256 groups.)  Between 768 and 1024 groups the same kernel with
-// TWO waves per group (128 VGPRs, 4 waves per SIMD: all 2048 waves resident) is the fastest form:
-// 176 / 256 us at 1024 groups; at 1536 groups and beyond one block per lane wins (256 vs 286 us).
-// QS_HIP_DP=0 switches the small-plane kernel off (A/B runs, tests of both forms);
+// Which form of pass B a launch of `groups` 64-block groups gets.  Measured on MI355X
+// (tools/bench_sizes.py, profiles/r02f_small_planes/run11_*; us per launch, q3 / q4):
+//   groups   one block per lane   diagonal-parallel, 4 waves   2 waves
+//   <= 256        199 / 295             82 / 114               122 / 176
+//      512        203 / 301             99 / 142               143 / 211
+//      768        208 / 309            128 / 195               147 / 218
+//     1024        215 / 319            180 / 266               157 / 235
+//     1536        255 / 380            241 / 362               208 / 325
+//     2048        264 / 397            312 / 473               316 / 484
+// 4 waves per group = one per SIMD, three workgroups per CU at the kernel's 3 waves per SIMD: all
+// resident up to 768 groups; 2 waves per group keeps up to 1280 groups resident (LDS-bound: 26.7 KB
+// per workgroup) and wins up to 1536; beyond that the chip is full anyway and one block per lane
+// does the least work.  (6 waves per group were tried: a 6-wave workgroup puts two waves on two of
+// the four SIMDs, only ONE such workgroup fits a CU, and it is no faster than 4 waves even below 256
+// groups.)  QS_HIP_DP=0 switches the small-plane kernel off (A/B runs, tests of both forms);
 // QS_HIP_DP_GROUPS / QS_HIP_DP_GROUPS2 move the two limits.
 #define QS_DP_WAVES 4
 static int qs_dp_waves(int groups) {
   static const int on = [] { const char* v = getenv("QS_HIP_DP"); return v ? atoi(v) : 1; }();
   static const int lim = [] { const char* v = getenv("QS_HIP_DP_GROUPS"); return v ? atoi(v) : 768; }();
-  static const int lim2 = [] { const char* v = getenv("QS_HIP_DP_GROUPS2"); return v ? atoi(v) : 1024; }();
+  static const int lim2 = [] { const char* v = getenv("QS_HIP_DP_GROUPS2"); return v ? atoi(v) : 1536; }();
   if (!on) return 0;
   return groups <= lim ? QS_DP_WAVES : groups <= lim2 ? 2 : 0;
 }
