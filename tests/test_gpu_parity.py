@@ -521,3 +521,25 @@ def test_gpu_fuzz_corpus_every_pass_b_form(env):
     out = _run_py("import runpy, sys; sys.argv = ['fuzz_gpu.py', 'run', 'tests/golden/fuzz_s2.jsonl']; "
                   "runpy.run_path('tools/fuzz_gpu.py', run_name='__main__')", env)
     assert "400 trials, 959 jobs" in out and " 0 failures" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(65500, 8), (8, 65500), (65500, 24), (8, 8), (16, 16), (24, 8)])
+def test_gpu_extreme_geometry(gpu, oracle, synth, size):
+    """JPEG's limits: the widest (8,188 blocks in one block row) and the tallest (8,188 block rows of
+    one block) image, and the smallest ones -- gray and 4:2:0 (chroma planes of a single block),
+    every route: one call, sharded over three logical devices, --quality 3 / 4 / 6"""
+    w, h = size
+    coef, quant = synth.synth_gray(w, h, 50, seed=w + h)
+    for flags in (0, 1):
+        want = oracle.do_quantsmooth([coef], [quant], flags, 2, threads=0)
+        assert_same_result(gpu.do_quantsmooth([coef], [quant], flags, 2), want, f"gray {size} flags={flags}")
+        assert_same_result(gpu.do_quantsmooth([coef], [quant], flags, 2, devices=[0, 0, 0]), want, f"gray {size} flags={flags} sharded")
+    if w <= 4096 or h <= 24:
+        j = synth.synth_ycc(w, h, 2, 2, quality=50, seed=3)
+        kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(w, h))
+        for flags in (0, 7):
+            want = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, 2, threads=0, **kw)
+            assert_same_result(gpu.do_quantsmooth(j["coefs"], j["quants"], flags, 2, **kw), want, f"ycc {size} flags={flags}")
+            assert_same_result(gpu.do_quantsmooth(j["coefs"], j["quants"], flags, 2, devices=[0, 0], **kw), want,
+                               f"ycc {size} flags={flags} sharded")
