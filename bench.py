@@ -279,8 +279,8 @@ def main():
                        "sharding": "none" if world == 1 else f"{world} block-row bands, 1-pixel-row halo over "
                                                                f"{'RCCL' if args.backend == 'nccl' else 'gloo (host-staged)'} per iteration, "
                                                                + ("exchange overlapped with the interior rows" if args.overlap
-                                                                  else "the planes of a step advance together: one batched exchange per "
-                                                                       "iteration between pass A and pass B, in stream order"),
+                                                                  else "the planes of a step advance together as a plane set: one launch per "
+                                                                       "pass and one batched exchange per iteration, in stream order"),
                        "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
                        "blocks_per_gpu": res["blocks_per_gpu"], **({"comm_note": comm_note} if comm_note else {})},
             "roofline": {"bound": "hbm", "kernel": res["kernel"], "achieved": achieved_gbs,
@@ -372,7 +372,11 @@ def run_luma(c):
     def one_step_sharded(planes):
         for e, p in zip(engs, planes):
             e.rebind(p)
-        bands.run_bands_batched(engs, topo, args.niter, lambda: exch_many(engs, topo, dist))
+        # ... and ONE launch per pass: the bands of the 12 planes travel as a plane set, so that a 1/8
+        # band (2048 waves, two per SIMD) does not run alone on a chip that holds three per SIMD
+        for lo in range(0, len(engs), 48):
+            part = engs[lo:lo + 48]
+            bands.run_bands_batched_sets(hip, part, topo, args.niter, lambda: exch_many(part, topo, dist))
 
     def one_plane(coef, timed):
         eng.rebind(coef)

@@ -160,6 +160,22 @@ def run_bands_batched(engines, topo: BandTopology, niter: int, exchange_many) ->
             e.smooth(it == niter - 1)
 
 
+def run_bands_batched_sets(hip, engines, topo: BandTopology, niter: int, exchange_many, stream=None) -> None:
+    """run_bands_batched with ONE launch per pass for all planes of the batch (plane sets,
+    qs_hip_idct_planes / qs_hip_smooth_planes): a 1/8 band of an 8192^2 plane is 2048 waves, two per
+    SIMD -- launched alone it runs at 72 % of the rate the same kernel reaches once the chip is full
+    (DESIGN.md 4.2b table); twelve bands in one launch fill it.  HipBandEngine objects only."""
+    band = (1 if topo.up is not None else 0) | (2 if topo.down is not None else 0)
+    flags = engines[0].flags
+    s = stream if stream is not None else engines[0]._s()
+    for it in range(niter):
+        refs = hip.plane_refs([(e.cst.data_ptr(), e.coef.data_ptr(), e.plane.data_ptr(), e.status.data_ptr(),
+                                e.wblk, e.hblk, e.luma, band) for e in engines])
+        hip.idct_planes(refs, it == 0, s)
+        exchange_many()
+        hip.smooth_planes(refs, flags, it == niter - 1, s)
+
+
 def exchange_halo_local(engines) -> None:
     """the same exchange between N logical bands living in one process
     (device-to-device copies): used to test the band logic on a single GPU"""

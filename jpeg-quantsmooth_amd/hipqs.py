@@ -272,11 +272,14 @@ class HipQS:
 
     @staticmethod
     def plane_refs(planes):
-        """[(d_consts, d_coef, d_plane, d_status, wblk, hblk, luma)] -> ctypes array for the *_planes calls"""
+        """[(d_consts, d_coef, d_plane, d_status, wblk, hblk, luma[, band])] -> ctypes array for the *_planes
+        calls; band: bit 0 / bit 1 = the top / bottom apron row is a halo row (a band of a sharded plane)"""
         arr = (PlaneRef * len(planes))()
-        for r, (cst, coef, plane, status, wb, hb, luma) in zip(arr, planes):
+        for r, p in zip(arr, planes):
+            cst, coef, plane, status, wb, hb, luma = p[:7]
             r.d_consts, r.d_coef, r.d_plane, r.d_status = cst, coef, plane, status
             r.wblk, r.hblk, r.luma = wb, hb, int(luma)
+            r.band = int(p[7]) if len(p) > 7 else 0
         return arr
 
     def idct_planes(self, refs, first, stream=None):
