@@ -5,26 +5,28 @@ Metric (BASELINE.json): 8x8 blocks/s at q=3 niter=3 on a synthetic 8192x8192 lum
 plane, inputs resident in HBM.  A "step" is one pass of the hot path over one BATCH of
 synthetic input: `--batch` (default 12) independent 8192x8192 planes, each taken through
 a complete do_quantsmooth -- niter x {IDCT-to-plane kernel, [halo exchange], recovery
-kernel}, final clamp fused into the last recovery launch.  (The batch only makes a step
-long enough that the driver's 20 timed steps cover about a second, i.e. the power-capped
-steady state; `value` counts blocks, so it does not depend on the batch size.)
+kernel}, final clamp fused into the last recovery launch.  The planes of a step travel
+together as one plane set: one launch per pass covers all of them (the job layer's
+qs_hip_idct_planes / qs_hip_smooth_planes), at every N.  (20 driver steps of 12 planes cover
+about a second, i.e. the power-capped steady state; `value` counts blocks.)
 
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: every plane is split into N contiguous block-row bands (strong scaling, total
 work fixed, as BASELINE.json's north_star asks); after each IDCT pass a band swaps one
-pixel row with each neighbour over RCCL (torch.distributed send/recv), which is the only
-data-path communication the algorithm has.
+pixel row with each neighbour over RCCL (torch.distributed send/recv, ONE batched call for
+the 12 planes of the step), which is the only data-path communication the algorithm has
+(SURVEY.md section 8e).
 
 Workloads (BASELINE.json configs): default = 8192^2 luma, --quality 3 (the metric) or 4
 (configs[2]); --size 16384 (configs[3]); --quality 5/6 = 8192^2 4:2:0 YCbCr with
 JOINT_YUV (+ UPSAMPLE_UV), niter 5 (configs[4], cross-component stages, colour bands).
 
 One JSON line is printed by rank 0.  `roofline` is for the dominant kernel
-(qs_smooth_plane_kernel): achieved = algorithmic bytes (256 B per block per launch:
-read + write of 64 int16) / mean launch time measured with HIP events on the launch
-stream.  The kernel is FP32-VALU-bound, so `roofline_valu` gives the fraction of the
+(qs_smooth_set_kernel, one launch = the 12 planes of a step): achieved = algorithmic bytes
+(256 B per block per launch: read + write of 64 int16) / mean launch time measured with HIP
+events on the launch stream.  The kernel is FP32-VALU-bound, so `roofline_valu` gives the fraction of the
 non-FMA FP32 vector peak, which is the roofline that actually binds.
 `verify_ok`: the last timed step's result is compared with the CPU oracle on 16 block
 rows at the top, in the middle and at the bottom of the plane (N > 1: also on the rows
@@ -250,7 +252,7 @@ def main():
         value = res["total_blocks"] * args.steps / res["elapsed"]
         kern_ms = res["kern_ms"]
         if kern_ms is None:   # sharded run: no per-kernel events; derive from the step time (comm included)
-            kern_ms = res["elapsed"] / args.steps / res["batch"] / args.niter * 1e3
+            kern_ms = res["elapsed"] / args.steps / res["launches_per_step"] * 1e3
         kblocks = res["kernel_blocks"]
         achieved_gbs = kblocks * ALGO_BYTES_PER_BLOCK_ITER / (kern_ms * 1e-3) / 1e9
         achieved_tf = kblocks * FLOP_PER_BLOCK_ITER[flags & 1] / (kern_ms * 1e-3) / 1e12
@@ -259,8 +261,14 @@ def main():
         if pmc.exists() and not colour and world == 1:
             try:
                 j = json.loads(pmc.read_text())
-                traffic = j.get(f"q{args.quality}_{size}")
+                ppl = res.get("planes_per_launch", 1)
+                traffic = j.get(f"q{args.quality}_{size}_set{ppl}") if ppl > 1 else None
                 traffic_src = j.get("_source")
+                if traffic is None:
+                    traffic = j.get(f"q{args.quality}_{size}")
+                    if traffic is not None and ppl > 1:           # only single-plane counters on file
+                        traffic *= ppl
+                        traffic_src = f"{ppl} x the per-plane figure of " + str(traffic_src)
             except Exception:
                 traffic = None
         out = {
@@ -288,6 +296,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
                          "kernel_launches_timed": res["kernel_launches"],
                          "algorithmic_bytes_per_launch": kblocks * ALGO_BYTES_PER_BLOCK_ITER,
+                         "planes_per_launch": res.get("planes_per_launch", 1),
                          "note": "kernel is FP32-VALU-bound (~290 flop/B); see roofline_valu"},
             "roofline_valu": {"bound": "fp32-valu (separate mul/add, FMA forbidden by bit-exactness)",
                               "achieved": achieved_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -363,31 +372,38 @@ def run_luma(c):
     is_band = topo.up is not None or topo.down is not None
     comm = eng.comm_scope() if (is_band and args.overlap) else None
     exch = bands.exchange_halo_dist if args.backend == "nccl" else bands.exchange_halo_dist_hostcopy
-    # sharded default: the planes of a step advance together, so that each iteration has ONE batched
-    # halo exchange for all of them (the exchange is latency-bound: 2 rows of 8 KB per plane)
+    # Default schedule at every N: the planes of a step advance together as ONE plane set -- one launch
+    # per pass for all of them (a lone 1/8 band leaves the chip two-thirds idle; at N = 1 it saves the
+    # twelve launch tails) and, for N > 1, ONE batched halo exchange per iteration (latency-bound: 2 rows
+    # of 8 KB per plane).  --overlap keeps the older per-plane schedule.
     engs = [eng] + [bands.HipBandEngine(hip, torch, work[0][b], quant, flags, luma=1, device=dev)
-                    for b in range(1, batch)] if (is_band and not args.overlap) else None
+                    for b in range(1, batch)] if not args.overlap else None
     exch_many = bands.exchange_halo_dist_many if args.backend == "nccl" else bands.exchange_halo_dist_many_hostcopy
+    pending = []
 
-    def one_step_sharded(planes):
+    def mark(which):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        if which == 0:
+            pending.append(ev)
+        else:
+            ev_pairs.append((pending.pop(), ev))
+
+    def one_step_sharded(planes, timed=False):
         for e, p in zip(engs, planes):
             e.rebind(p)
-        # ... and ONE launch per pass: the bands of the 12 planes travel as a plane set, so that a 1/8
-        # band (2048 waves, two per SIMD) does not run alone on a chip that holds three per SIMD
-        for lo in range(0, len(engs), 48):
+        for lo in range(0, len(engs), 48):               # (a plane set holds up to 56 planes)
             part = engs[lo:lo + 48]
-            bands.run_bands_batched_sets(hip, part, topo, args.niter, lambda: exch_many(part, topo, dist))
+            bands.run_bands_batched_sets(hip, part, topo, args.niter,
+                                         (lambda: exch_many(part, topo, dist)) if is_band else (lambda: None),
+                                         mark=mark if timed else None)
 
     def one_plane(coef, timed):
+        """--overlap only: one plane at a time, bands.run_band_overlapped (interior rows on the main
+        stream, halo exchange + edge rows on a side stream)"""
         eng.rebind(coef)
         if is_band:
-            # default: pass A, halo exchange, pass B in stream order (bands.run_band); --overlap:
-            # bands.run_band_overlapped.  Per-kernel event timing is an N = 1 matter (roofline is
-            # reported there)
-            if args.overlap:
-                bands.run_band_overlapped(eng, topo, args.niter, lambda: exch(eng, topo, dist), comm=comm)
-            else:
-                bands.run_band(eng, topo, args.niter, lambda: exch(eng, topo, dist))
+            bands.run_band_overlapped(eng, topo, args.niter, lambda: exch(eng, topo, dist), comm=comm)
             return
         for it in range(args.niter):
             eng.idct(it == 0, topo.rep_top, topo.rep_bot)
@@ -409,7 +425,7 @@ def run_luma(c):
     t0 = time.perf_counter()
     for i in range(args.steps):
         if engs:
-            one_step_sharded(work[args.warmup + i])
+            one_step_sharded(work[args.warmup + i], timed=not is_band)
         else:
             for bi, p in enumerate(work[args.warmup + i]):
                 one_plane(p, bi == 0)                    # HIP events around the first plane's launches of every step
@@ -418,8 +434,13 @@ def run_luma(c):
     assert not any(e.bad_coef() for e in (engs or [eng])), "range check tripped on synthetic input"
     last = work[-1][-1]                                   # the last plane of the last timed step
 
+    set_launch = engs is not None                         # the timed launches cover all planes of the step
     res = dict(elapsed=elapsed, batch=batch, total_blocks=total_blocks_plane * batch, blocks_per_gpu=hblk * wblk,
-               kernel=f"qs_smooth_plane_kernel<{'true' if flags & 1 else 'false'}>", kernel_blocks=hblk * wblk,
+               kernel=(f"qs_smooth_set_kernel<{'true' if flags & 1 else 'false'}> (one launch = the {batch} planes of a step)"
+                       if set_launch else f"qs_smooth_plane_kernel<{'true' if flags & 1 else 'false'}>"),
+               kernel_blocks=hblk * wblk * (min(batch, 48) if set_launch else 1),
+               planes_per_launch=min(batch, 48) if set_launch else 1,
+               launches_per_step=args.niter * (-(-batch // 48) if set_launch else batch),
                kern_ms=float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else None,
                kernel_launches=len(ev_pairs),
                workload=f"{size}x{size} luma plane ({hblk_total * wblk} blocks)")
@@ -532,7 +553,7 @@ def run_colour(c):
                kernel=f"qs_smooth_plane_kernel<{'true' if flags & 1 else 'false'}> (luma plane)",
                kernel_blocks=(y1 - y0) * wby,
                kern_ms=float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else None,
-               kernel_launches=len(ev_pairs),
+               kernel_launches=len(ev_pairs), launches_per_step=args.niter * batch,
                workload=f"{size}x{size} 4:2:0 YCbCr image ({hby * wby} + 2 x {hbc * (wby // 2)} blocks)")
     if c["verify"] and c["sharded"] and small:
         # functional runs of the sharded path: every rank checks its whole band against the oracle's

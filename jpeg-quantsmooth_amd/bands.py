@@ -160,7 +160,7 @@ def run_bands_batched(engines, topo: BandTopology, niter: int, exchange_many) ->
             e.smooth(it == niter - 1)
 
 
-def run_bands_batched_sets(hip, engines, topo: BandTopology, niter: int, exchange_many, stream=None) -> None:
+def run_bands_batched_sets(hip, engines, topo: BandTopology, niter: int, exchange_many, stream=None, mark=None) -> None:
     """run_bands_batched with ONE launch per pass for all planes of the batch (plane sets,
     qs_hip_idct_planes / qs_hip_smooth_planes): a 1/8 band of an 8192^2 plane is 2048 waves, two per
     SIMD -- launched alone it runs at 72 % of the rate the same kernel reaches once the chip is full
@@ -173,7 +173,11 @@ def run_bands_batched_sets(hip, engines, topo: BandTopology, niter: int, exchang
                                 e.wblk, e.hblk, e.luma, band) for e in engines])
         hip.idct_planes(refs, it == 0, s)
         exchange_many()
+        if mark:
+            mark(0)                                  # (bench.py: HIP events around the pass-B launch)
         hip.smooth_planes(refs, flags, it == niter - 1, s)
+        if mark:
+            mark(1)
 
 
 def exchange_halo_local(engines) -> None:

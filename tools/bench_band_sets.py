@@ -64,7 +64,7 @@ def run(world, sets, steps=6):
 
 
 base = run(1, False)
-print(f"q{args.quality}: one GPU, whole plane: {base:.3f} ms per plane")
+print(f"q{args.quality}: one GPU, whole plane: {base:.3f} ms per plane   (as one plane set of {args.batch}: {run(1, True):.3f} ms)")
 for world in (2, 4, 8):
     a, b = run(world, False), run(world, True)
     print(f"  1/{world} band: per-plane launches {a:.3f} ms ({base / a:.2f}x)   plane-set launches {b:.3f} ms ({base / b:.2f}x)", flush=True)
