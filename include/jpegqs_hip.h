@@ -87,8 +87,10 @@ int qs_hip_do_quantsmooth_rows(qs_hip_job *job, int16_t *const *const *rows, int
  * as a group; the others go through qs_hip_do_quantsmooth, up to four at a time from helper
  * threads (their error text is not kept: results[i] carries the code).  results[i] =
  * what qs_hip_do_quantsmooth would have returned for jobs[i].  Returns 0, or < 0 when
- * the batch as a whole could not run (bad arguments, no device).  Not part of the
- * reference API: an addition for callers that serve many images. */
+ * the batch as a whole could not run (bad arguments, no device).  With several devices
+ * configured (qs_hip_set_devices / QS_HIP_DEVICES / all visible) the jobs of a batch are spread
+ * over them as whole jobs, balanced by block count: independent objects, no exchange.  Not part
+ * of the reference API: an addition for callers that serve many images. */
 int qs_hip_do_quantsmooth_batch(qs_hip_job *const *jobs, int njobs, int flags, int niter, int *results);
 
 /* ---- several GPUs, one host process (the reference's counterpart is the

@@ -649,44 +649,72 @@ static int do_quantsmooth_batch_impl(qs_hip_job* const* jobs, int njobs, int fla
   if (fused.empty() && single.empty()) return QS_HIP_OK;
   if (qs_hip_device_count() <= 0)
     return qs_fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
-  if (!fused.empty()) {
-    for (int j : fused) results[j] = QS_HIP_ENODEV;
-    const double t0 = wall_ms();
-    const int r = run_fused(jobs, fused, flags, nit, results);
-    if (trace_on()) fprintf(stderr, "qs_hip trace: batch  run_fused total %.2f ms\n", wall_ms() - t0);
-    if (r) return r;
-  }
-  // Coupled / special jobs take the general route, which is a chain of small launches per job
-  // (a full-HD --quality 6 frame: 1.75 ms, most of it kernel latency).  Up to four of them are in
-  // flight at a time, each from its own host thread with its own stream set (the job layer is
-  // thread-safe), so that their kernels and transfers overlap; jobs large enough to be spread over
-  // several GPUs run alone.
+  // Jobs large enough to be cut over several GPUs run alone (run_sharded); everything else is spread
+  // over the configured devices as WHOLE jobs -- independent objects, no exchange between devices:
+  // every device gets a share of the plane-set jobs (one run_fused per device) and of the coupled /
+  // special jobs (general route, a chain of small launches per job: up to four in flight per device,
+  // each from its own host thread with its own stream set -- the job layer is thread-safe).
   std::vector<int> small, large;
   for (int j : single) (shard_devices_for(jobs[j], flags, nit).empty() ? small : large).push_back(j);
-  const int nthreads = (int)std::min<size_t>(4, small.size());
-  if (nthreads > 1) {
-    const int dev = current_device();
-    std::atomic<size_t> next{0};
-    auto worker = [&]() {
-      (void)hipSetDevice(dev);                               // (a new thread starts on device 0)
-      for (size_t n; (n = next.fetch_add(1)) < small.size();) {
-        const int j = small[n];
-        try {
-          results[j] = do_quantsmooth_impl(jobs[j], flags, niter, 0, nullptr, nullptr);
-        } catch (const std::bad_alloc&) {
-          results[j] = QS_HIP_ENOMEM;
-        } catch (...) {
-          results[j] = QS_HIP_ENODEV;
-        }
-      }
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
-    worker();
-    for (auto& t : pool) t.join();
-  } else {
-    for (int j : small) results[j] = do_quantsmooth_impl(jobs[j], flags, niter, 0, nullptr, nullptr);
+  std::vector<int> devs = configured_devices();
+  if (devs.empty() || fused.size() + small.size() < 2) devs.assign(1, current_device());
+  const size_t nd = devs.size();
+  std::vector<std::vector<int>> fused_of(nd);
+  {                                                           // greedy balance by block count
+    std::vector<size_t> load(nd, 0);
+    std::vector<int> order(fused);
+    auto blocks_of = [&](int j) { size_t b = 0; for (int ci = 0; ci < jobs[j]->ncomp; ++ci) b += (size_t)jobs[j]->wblk[ci] * jobs[j]->hblk[ci]; return b; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return blocks_of(a) > blocks_of(b); });
+    for (int j : order) {
+      const size_t d = std::min_element(load.begin(), load.end()) - load.begin();
+      fused_of[d].push_back(j); load[d] += blocks_of(j);
+    }
+    for (auto& v : fused_of) std::sort(v.begin(), v.end());
   }
+  for (int j : fused) results[j] = QS_HIP_ENODEV;
+  std::atomic<size_t> next_small{0};
+  std::atomic<int> first_error{0};
+  auto run_small = [&]() {
+    for (size_t n; (n = next_small.fetch_add(1)) < small.size();) {
+      const int j = small[n];
+      try {
+        results[j] = do_quantsmooth_impl(jobs[j], flags, niter, 0, nullptr, nullptr);
+      } catch (const std::bad_alloc&) {
+        results[j] = QS_HIP_ENOMEM;
+      } catch (...) {
+        results[j] = QS_HIP_ENODEV;
+      }
+    }
+  };
+  auto device_worker = [&](size_t d, bool with_fused) {
+    (void)hipSetDevice(devs[d]);                              // (a new thread starts on device 0)
+    try {
+      if (with_fused && !fused_of[d].empty())
+        if (int r = run_fused(jobs, fused_of[d], flags, nit, results)) { int z = 0; first_error.compare_exchange_strong(z, r); }
+    } catch (const std::bad_alloc&) {
+      int z = 0; first_error.compare_exchange_strong(z, (int)QS_HIP_ENOMEM);
+    } catch (...) {
+      int z = 0; first_error.compare_exchange_strong(z, (int)QS_HIP_ENODEV);
+    }
+    run_small();
+  };
+  const double t0 = wall_ms();
+  if (nd == 1 && small.size() < 2) {
+    device_worker(0, true);                                   // the common case: everything on the calling thread
+  } else {
+    const int home = current_device();
+    const size_t extra = small.size() >= 2 ? std::min<size_t>(3, small.size() - 1) : 0;   // more threads for the coupled jobs
+    std::vector<std::thread> pool;
+    for (size_t d = 1; d < nd; ++d) pool.emplace_back(device_worker, d, true);
+    for (size_t d = 0; d < nd; ++d)
+      for (size_t t = 0; t < extra; ++t) pool.emplace_back(device_worker, d, false);
+    device_worker(0, true);
+    for (auto& t : pool) t.join();
+    (void)hipSetDevice(home);
+  }
+  if (trace_on()) fprintf(stderr, "qs_hip trace: batch  %zu plane-set + %zu coupled job(s) on %zu device(s): %.2f ms\n",
+                          fused.size(), small.size(), nd, wall_ms() - t0);
+  if (first_error.load()) return qs_fail(first_error.load(), "qs_hip_do_quantsmooth_batch: a device worker failed (results[] carries the per-job codes)");
   for (int j : large) results[j] = do_quantsmooth_impl(jobs[j], flags, niter, 0, nullptr, nullptr);
   return QS_HIP_OK;
 }

@@ -47,5 +47,7 @@ int run_sharded(qs_hip_job* job, int flags, int niter, const std::vector<int>& d
 // the configured device list (qs_hip_set_devices / QS_HIP_DEVICES / all visible devices) when
 // this job should be sharded, empty otherwise
 std::vector<int> shard_devices_for(const qs_hip_job* job, int flags, int niter);
+// the configured device list itself (qs_hip_set_devices, else QS_HIP_DEVICES, else all visible devices)
+std::vector<int> configured_devices();
 
 }  // namespace qsj

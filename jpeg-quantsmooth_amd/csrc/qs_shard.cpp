@@ -558,14 +558,17 @@ static bool colour_shardable(const qs_hip_job* job, int flags, int niter) {
 
 }  // namespace
 
-std::vector<int> qsj::shard_devices_for(const qs_hip_job* job, int flags, int niter) {
+std::vector<int> qsj::configured_devices() {
   std::vector<int> devs;
-  {
-    std::lock_guard<std::mutex> lk(g_cfg_mu);
-    if (g_cfg_set) devs = g_cfg_devices;
-    else if (const char* v = getenv("QS_HIP_DEVICES")) devs = parse_devices(v);
-    else { const int n = qs_hip_device_count(); for (int i = 0; i < n; ++i) devs.push_back(i); }
-  }
+  std::lock_guard<std::mutex> lk(g_cfg_mu);
+  if (g_cfg_set) devs = g_cfg_devices;
+  else if (const char* v = getenv("QS_HIP_DEVICES")) devs = parse_devices(v);
+  else { const int n = qs_hip_device_count(); for (int i = 0; i < n; ++i) devs.push_back(i); }
+  return devs;
+}
+
+std::vector<int> qsj::shard_devices_for(const qs_hip_job* job, int flags, int niter) {
+  std::vector<int> devs = configured_devices();
   if (devs.size() < 2) return {};
   const size_t min_blocks = env_size("QS_HIP_SHARD_MIN_BLOCKS", (size_t)512 << 10);   // (read per call: tests lower it)
   size_t blocks = 0;

@@ -153,3 +153,26 @@ def test_job_given_as_rows_equals_contiguous(gpu, oracle, synth, padded):
                 assert np.array_equal(got, want["coefs"][ci]), (flags, ci, padded)
             if padded:
                 assert not store[ci][:, work[ci].shape[1]:].any()      # nothing written beyond width_in_blocks
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,niter", [(0, 3), (1, 2), (7, 2), (11, 1)])
+def test_batch_spread_over_devices(gpu, oracle, synth, flags, niter):
+    """qs_hip_do_quantsmooth_batch with several devices configured: whole jobs go to different devices
+    (independent objects, no exchange) -- plane-set jobs as one group per device, coupled jobs from
+    worker threads per device; three logical devices on the one GPU here"""
+    jobs = []
+    for n, (w, h, samp) in enumerate([(200, 136, (2, 2)), (96, 64, (1, 1)), (333, 217, (2, 2)), (64, 64, (2, 1)),
+                                      (160, 120, (2, 2)), (72, 40, (1, 1)), (256, 160, (2, 2))]):
+        j = synth.synth_ycc(w, h, samp[0], samp[1], quality=40 + 5 * n, seed=30 + n)
+        jobs.append(dict(coefs=j["coefs"], quants=j["quants"], hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(w, h)))
+    coef, quant = synth.synth_gray(120, 88, 50, seed=5)
+    jobs.append(dict(coefs=[coef], quants=[quant]))
+    gpu.set_devices([0, 0, 0])
+    try:
+        got = gpu.do_quantsmooth_batch(jobs, flags, niter)
+    finally:
+        gpu.set_devices([])
+    for n, (j, g) in enumerate(zip(jobs, got)):
+        kw = {k: j[k] for k in ("hsamp", "vsamp", "colorspace", "image_size") if k in j}
+        assert_same_result(g, oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw), f"job {n} flags={flags}")
