@@ -288,7 +288,8 @@ def main():
                                                                f"{'RCCL' if args.backend == 'nccl' else 'gloo (host-staged)'} per iteration, "
                                                                + ("exchange overlapped with the interior rows" if args.overlap
                                                                   else "the planes of a step advance together as a plane set: one launch per "
-                                                                       "pass and one batched exchange per iteration, in stream order"),
+                                                                       "pass and one packed send + receive per neighbour and iteration, "
+                                                                       "in stream order"),
                        "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
                        "blocks_per_gpu": res["blocks_per_gpu"], **({"comm_note": comm_note} if comm_note else {})},
             "roofline": {"bound": "hbm", "kernel": res["kernel"], "achieved": achieved_gbs,
@@ -366,7 +367,10 @@ def run_luma(c):
     del full
 
     work = [[pristine.clone() for _ in range(batch)] for _ in range(nsteps)]   # resident inputs, one set per step
-    eng = bands.HipBandEngine(hip, torch, work[0][0], quant, flags, luma=1, device=dev)
+    # the pixel planes of the batch live in one [batch, plane_bytes] tensor: the halo rows of all of them
+    # are then packed / unpacked with one strided copy each (bands.exchange_halo_packed)
+    planes2d = torch.zeros((batch, (hip.plane_bytes(wblk, hblk) + 255) & ~255), dtype=torch.uint8, device=dev)
+    eng = bands.HipBandEngine(hip, torch, work[0][0], quant, flags, luma=1, device=dev, plane=planes2d[0])
     stream = torch.cuda.current_stream()
     ev_pairs = []
     is_band = topo.up is not None or topo.down is not None
@@ -376,9 +380,11 @@ def run_luma(c):
     # per pass for all of them (a lone 1/8 band leaves the chip two-thirds idle; at N = 1 it saves the
     # twelve launch tails) and, for N > 1, ONE batched halo exchange per iteration (latency-bound: 2 rows
     # of 8 KB per plane).  --overlap keeps the older per-plane schedule.
-    engs = [eng] + [bands.HipBandEngine(hip, torch, work[0][b], quant, flags, luma=1, device=dev)
+    engs = [eng] + [bands.HipBandEngine(hip, torch, work[0][b], quant, flags, luma=1, device=dev, plane=planes2d[b])
                     for b in range(1, batch)] if not args.overlap else None
-    exch_many = bands.exchange_halo_dist_many if args.backend == "nccl" else bands.exchange_halo_dist_many_hostcopy
+
+    def exch_many(part, lo):
+        bands.exchange_halo_packed(hip, planes2d[lo:lo + len(part)], wblk, hblk, topo, dist, hostcopy=args.backend != "nccl")
     pending = []
 
     def mark(which):
@@ -395,7 +401,7 @@ def run_luma(c):
         for lo in range(0, len(engs), 48):               # (a plane set holds up to 56 planes)
             part = engs[lo:lo + 48]
             bands.run_bands_batched_sets(hip, part, topo, args.niter,
-                                         (lambda: exch_many(part, topo, dist)) if is_band else (lambda: None),
+                                         (lambda: exch_many(part, lo)) if is_band else (lambda: None),
                                          mark=mark if timed else None)
 
     def one_plane(coef, timed):
@@ -425,7 +431,7 @@ def run_luma(c):
     t0 = time.perf_counter()
     for i in range(args.steps):
         if engs:
-            one_step_sharded(work[args.warmup + i], timed=not is_band)
+            one_step_sharded(work[args.warmup + i], timed=True)
         else:
             for bi, p in enumerate(work[args.warmup + i]):
                 one_plane(p, bi == 0)                    # HIP events around the first plane's launches of every step

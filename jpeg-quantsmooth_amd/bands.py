@@ -149,6 +149,36 @@ def exchange_halo_dist_many_hostcopy(engines, topo: BandTopology, dist) -> None:
         engine.row(dst_y).copy_(buf)
 
 
+def exchange_halo_packed(hip, planes2d, wblk: int, hblk: int, topo: BandTopology, dist, hostcopy: bool = False) -> None:
+    """The halo exchange of a whole batch with ONE send and ONE receive per neighbour: `planes2d` is the
+    [batch, plane_bytes] tensor whose rows are the engines' planes (same band geometry), so pixel row y of
+    every plane is the strided view planes2d[:, off(y) : off(y) + pitch]; it is packed into a contiguous
+    [batch, pitch] buffer by one copy kernel, sent, and the received buffer lands in the apron rows by one
+    strided copy.  hostcopy: stage through host memory (gloo)."""
+    pitch = hip.plane_pitch(wblk)
+    h = hblk * 8
+
+    def view(y):
+        o = hip.plane_row_offset(wblk, y)
+        return planes2d[:, o:o + pitch]
+    ops, recvs = [], []
+    for nbr, src_y, dst_y in ((topo.up, 0, -1), (topo.down, h - 1, h)):
+        if nbr is None:
+            continue
+        out = view(src_y).contiguous()
+        if hostcopy:
+            out = out.to("cpu")
+        buf = out.new_empty(out.shape)
+        ops.append(dist.P2POp(dist.isend, out, nbr))
+        ops.append(dist.P2POp(dist.irecv, buf, nbr))
+        recvs.append((dst_y, buf))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for dst_y, buf in recvs:
+        view(dst_y).copy_(buf)
+
+
 def run_bands_batched(engines, topo: BandTopology, niter: int, exchange_many) -> None:
     """one complete smoothing of the same band of several independent planes, iteration by
     iteration for all of them: niter x {pass A of every plane, ONE halo exchange, pass B of every plane}"""
@@ -235,14 +265,17 @@ def run_band_overlapped(engine: BandEngine, topo: BandTopology, niter: int, exch
 class HipBandEngine(BandEngine):
     """band backend on the MI355X kernels; all buffers are torch device tensors"""
 
-    def __init__(self, hip, torch, coef, quant, flags, luma=1, device=None, stream=None):
+    def __init__(self, hip, torch, coef, quant, flags, luma=1, device=None, stream=None, plane=None):
         self.hip, self.torch = hip, torch
         self.coef = coef                                   # int16 [hblk, wblk, 64] on device
         self.hblk, self.wblk = int(coef.shape[0]), int(coef.shape[1])
         self.flags, self.luma = flags, luma
         dev = device if device is not None else coef.device
         self.cst = torch.from_numpy(hip.consts_build(quant, flags)).to(dev)
-        self.plane = torch.zeros(hip.plane_bytes(self.wblk, self.hblk), dtype=torch.uint8, device=dev)
+        # plane: a caller-owned uint8 tensor of plane_bytes (e.g. one row of a [batch, plane_bytes] tensor, so
+        # that the halo rows of a whole batch can be packed with one strided copy: exchange_halo_packed)
+        self.plane = plane if plane is not None else \
+            torch.zeros(hip.plane_bytes(self.wblk, self.hblk), dtype=torch.uint8, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.pitch = hip.plane_pitch(self.wblk)
         self._stream = stream

@@ -11,7 +11,7 @@ APRON_X = 16  # QS_APRON_X in csrc/qs_device.h
 
 
 class OracleBandEngine:
-    def __init__(self, oracle, hip, coef, quant, flags, luma=1):
+    def __init__(self, oracle, hip, coef, quant, flags, luma=1, plane=None):
         self.o = oracle
         self.coef = np.ascontiguousarray(coef, dtype=np.int16)   # updated in place
         self.hblk, self.wblk = self.coef.shape[:2]
@@ -19,7 +19,7 @@ class OracleBandEngine:
         self.flags, self.luma = flags, luma
         self.pitch = hip.plane_pitch(self.wblk)
         self._row_off = lambda y: hip.plane_row_offset(self.wblk, y)
-        self.plane = torch.zeros(hip.plane_bytes(self.wblk, self.hblk), dtype=torch.uint8)
+        self.plane = plane if plane is not None else torch.zeros(hip.plane_bytes(self.wblk, self.hblk), dtype=torch.uint8)
         self._bad = C.c_int(0)
         lib = oracle.lib
         self._idct = lib.qso_band_idct

@@ -67,7 +67,7 @@ def test_bands_gloo_equal_unsharded(world, overlapped, flags, oracle, synth, tmp
     assert np.array_equal(got, want)
 
 
-def _batched_worker(rank, world, port, tmp):
+def _batched_worker(rank, world, port, tmp, packed=False):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
     import torch
     import torch.distributed as dist
@@ -80,24 +80,32 @@ def _batched_worker(rank, world, port, tmp):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     engs = []
-    for seed in (21, 22, 23):                                    # three independent planes = one batch
+    hip = pkg.HipQS()
+    r0, r1 = bands.band_rows(25, world, rank)
+    planes2d = torch.zeros((3, (hip.plane_bytes(17, r1 - r0) + 255) & ~255), dtype=torch.uint8)
+    for n, seed in enumerate((21, 22, 23)):                      # three independent planes = one batch
         coef, quant = pkg.synth.synth_gray(136, 200, 45, seed=seed)
-        r0, r1 = bands.band_rows(coef.shape[0], world, rank)
-        engs.append(OracleBandEngine(Oracle(), pkg.HipQS(), coef[r0:r1].copy(), quant, 1))
+        assert coef.shape[:2] == (25, 17)
+        engs.append(OracleBandEngine(Oracle(), hip, coef[r0:r1].copy(), quant, 1, plane=planes2d[n] if packed else None))
     topo = bands.BandTopology(rank, world, r0, r1)
-    bands.run_bands_batched(engs, topo, 3, lambda: bands.exchange_halo_dist_many(engs, topo, dist))
+    if packed:        # the exchange bench.py uses: one packed send + receive per neighbour for the whole batch
+        bands.run_bands_batched(engs, topo, 3, lambda: bands.exchange_halo_packed(hip, planes2d, 17, r1 - r0, topo, dist))
+    else:
+        bands.run_bands_batched(engs, topo, 3, lambda: bands.exchange_halo_dist_many(engs, topo, dist))
     for n, e in enumerate(engs):
         np.save(os.path.join(tmp, f"plane{n}_band{rank}.npy"), e.coef)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_batched_bands_gloo_equal_unsharded(oracle, synth, tmp_path):
+@pytest.mark.parametrize("packed", [False, True])
+def test_batched_bands_gloo_equal_unsharded(packed, oracle, synth, tmp_path):
     """the schedule bench.py uses for N > 1: the planes of a batch advance together, ONE batched
-    halo exchange per iteration for all of them (world_size 3, gloo, CPU engine)"""
+    halo exchange per iteration for all of them -- per-plane messages, or (bench.py) the rows of the
+    whole batch packed into one message per neighbour (world_size 3, gloo, CPU engine)"""
     import torch.multiprocessing as mp
     world = 3
-    mp.spawn(_batched_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_batched_worker, args=(world, _free_port(), str(tmp_path), packed), nprocs=world, join=True)
     for n, seed in enumerate((21, 22, 23)):
         coef, quant = synth.synth_gray(136, 200, 45, seed=seed)
         want = oracle.do_quantsmooth([coef], [quant], 1, 3)["coefs"][0]

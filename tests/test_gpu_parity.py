@@ -392,6 +392,34 @@ def test_gpu_batch_many_planes_and_empty(gpu, oracle, synth):
         assert_same_result(a, b, f"job {k}")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,niter,couple_blocks", [(7, 3, None), (3, 2, None), (6, 1, "2000"), (7, 2, "1"), (2 | 32, 2, None)])
+def test_gpu_batch_coupled_groups(gpu, oracle, synth, flags, niter, couple_blocks, monkeypatch):
+    """coupled YCbCr jobs (JOINT_YUV / UPSAMPLE_UV, CLI --quality 5/6) of a batch advance in groups
+    (run_coupled: luma planes as one plane set, then chroma planes as one): every result as the oracle's
+    for that job alone -- more jobs than one group takes, subsampled and 4:4:4 jobs in one group, a job
+    that trips the range check inside a group (careful re-run, the others unaffected), group sizes forced
+    down to several groups / one job per task"""
+    if couple_blocks:
+        monkeypatch.setenv("QS_HIP_COUPLE_BLOCKS", couple_blocks)
+    jobs = []
+    layouts = [(2, 2), (1, 1), (2, 1), (1, 2), (2, 2)]
+    for k in range(34):
+        w, h = 40 + 8 * (k % 7) + (k % 3), 24 + 16 * (k % 4) + (k % 5)
+        hs, vs = layouts[k % len(layouts)]
+        j = synth.synth_ycc(w, h, hs, vs, quality=35 + (k % 4) * 15, seed=100 + k)
+        jobs.append(dict(coefs=j["coefs"], quants=j["quants"], hsamp=j["hsamp"], vsamp=j["vsamp"],
+                         colorspace=3, image_size=(w, h)))
+    bad = [c.copy() for c in jobs[5]["coefs"]]
+    bad[1][0, 0, 1] = 1500                                          # chroma coefficient far out of range
+    jobs[5] = dict(jobs[5], coefs=bad)
+    got = gpu.do_quantsmooth_batch(jobs, flags, niter)
+    for k, (j, a) in enumerate(zip(jobs, got)):
+        b = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, hsamp=j["hsamp"], vsamp=j["vsamp"],
+                                  colorspace=3, image_size=j["image_size"])
+        assert_same_result(a, b, f"coupled batch job {k} flags={flags} niter={niter}")
+
+
 def test_gpu_fuzz_corpus():
     """tests/golden/fuzz_s2.jsonl: 400 seeded trials (959 jobs: every flag combination, sizes up to
     1400x1050, all chroma layouts, extreme blocks, batches) whose expected output hashes were written
