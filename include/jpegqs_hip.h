@@ -85,7 +85,7 @@ int qs_hip_do_quantsmooth_rows(qs_hip_job *job, int16_t *const *const *rows, int
  * LOW_QUALITY: CLI --quality 3 and 4) are processed TOGETHER: one pass-A and one
  * pass-B launch per iteration over all their planes, so small images fill the 256 CUs
  * as a group; YCbCr jobs coupled by JOINT_YUV / UPSAMPLE_UV (--quality 5 and 6) advance in groups
- * of about 400k blocks (all luma planes as one launch per pass, then all chroma planes), the rest
+ * of about 200k blocks (all luma planes as one launch per pass, then all chroma planes), the rest
  * goes through qs_hip_do_quantsmooth -- groups and single jobs up to four at a time from helper
  * threads (their error text is not kept: results[i] carries the code).  results[i] =
  * what qs_hip_do_quantsmooth would have returned for jobs[i].  Returns 0, or < 0 when

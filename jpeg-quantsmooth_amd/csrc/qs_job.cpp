@@ -589,6 +589,36 @@ static bool job_couplable(const qs_hip_job* job, int flags, int niter) {
   return true;
 }
 
+// Groups arrive from several worker threads at once.  Left alone they move in lockstep -- all upload,
+// then all compute, then all download -- and nothing overlaps.  At most kSlots groups per device may
+// have kernels queued at a time: the others upload meanwhile and start computing when an earlier
+// group's kernels have finished and its results are on their way back.
+struct ComputeSlots {
+  std::mutex mu;
+  std::condition_variable cv;
+  int busy[64] = {0};
+  static ComputeSlots& get() { static ComputeSlots c; return c; }
+};
+struct ComputeSlot {
+  int dev; bool held = false;
+  explicit ComputeSlot(int d) : dev(d & 63) {
+    const int kSlots = (int)env_size("QS_HIP_COUPLE_SLOTS", 2);
+    ComputeSlots& c = ComputeSlots::get();
+    std::unique_lock<std::mutex> lk(c.mu);
+    c.cv.wait(lk, [&] { return c.busy[dev] < kSlots; });
+    ++c.busy[dev]; held = true;
+  }
+  void release() {
+    if (!held) return;
+    ComputeSlots& c = ComputeSlots::get();
+    { std::lock_guard<std::mutex> lk(c.mu); --c.busy[dev]; }
+    c.cv.notify_all(); held = false;
+  }
+  ~ComputeSlot() { release(); }
+  ComputeSlot(const ComputeSlot&) = delete;
+  ComputeSlot& operator=(const ComputeSlot&) = delete;
+};
+
 static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, int flags, int niter, int* results) {
   StreamLease lease;
   if (!lease.p) return qs_fail(QS_HIP_ENODEV, "could not create HIP streams: %s", hipGetErrorString(hipGetLastError()));
@@ -662,6 +692,7 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
     HIP_TRY(upload_pieces(coef.p, pieces, coef_bytes, s, stage));
   }
   HIP_TRY(hipMemsetAsync(status.p, 0, (size_t)G * 3 * sizeof(int32_t), s));
+  ComputeSlot slot(current_device());                        // (released when this group's kernels have finished)
 
   auto coef_of = [&](int g, int ci) { return reinterpret_cast<int16_t*>(coef.as<char>() + cj[g].coef_off[ci]); };
   auto plane_of = [&](int g, int ci) { return px.as<uint8_t>() + cj[g].px_off[ci]; };
@@ -748,6 +779,7 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
     }
   }
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(lease.p->luma_done, s));            // "this group's kernels are done"
 
   // ---- flags and results into pinned memory behind the kernels
   if (!hstatus.alloc((size_t)G * 3 * sizeof(int32_t))) return qs_fail(QS_HIP_ENOMEM, "out of pinned host memory");
@@ -760,6 +792,8 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
       HIP_TRY(down_up.back().issue(upc.as<char>() + cj[g].upc_off[k], cj[g].ubytes, s));
     }
   const double t_enq = wall_ms();
+  HIP_TRY(hipEventSynchronize(lease.p->luma_done));
+  slot.release();
   HIP_TRY(down.wait_first(s));
 
   // ---- scatter (the only place host memory is written); jobs whose range check tripped stay untouched
@@ -919,7 +953,7 @@ static int do_quantsmooth_batch_impl(qs_hip_job* const* jobs, int njobs, int fla
   }
   for (int j : fused) results[j] = QS_HIP_ENODEV;
   // the coupled YCbCr jobs among them advance in groups (run_coupled); what remains runs job by job
-  const size_t kCoupleBlocks = env_size("QS_HIP_COUPLE_BLOCKS", (size_t)400 << 10);   // (read per call: the tests lower it)
+  const size_t kCoupleBlocks = env_size("QS_HIP_COUPLE_BLOCKS", (size_t)200 << 10);   // (read per call: the tests lower it)
   std::vector<std::vector<int>> tasks;
   {
     std::vector<int> cur;

@@ -7,6 +7,7 @@ this script makes the job, checks one result against the oracle and prints the
 C program's JSON lines.
 
     python tools/bench_serving.py [width height [quality [niter]]]     default 1920 1080 3 3, 4:2:0
+    SERVING_CONFIGS=1x32,2x16 ...                                       only these threads x batch combinations
 """
 import struct
 import subprocess
@@ -45,7 +46,11 @@ libdir = Path(pkg.lib_path()).parent
 subprocess.check_call(["gcc", "-O2", "-o", str(exe), str(ROOT / "tools" / "bench_serving.c"), f"-I{ROOT / 'include'}",
                        f"-L{libdir}", "-ljpegqs_hip", f"-Wl,-rpath,{libdir}", "-lpthread"])
 print(f"# {w}x{h} 4:2:0 --quality {quality} --niter {niter}, {sum(c.shape[0] * c.shape[1] for c in j['coefs'])} blocks per image", flush=True)
-for nthreads, batch in ((1, 1), (2, 1), (4, 1), (8, 1), (16, 1), (1, 4), (1, 8), (1, 16), (1, 32), (2, 8), (2, 16), (4, 8), (4, 16)):
+import os  # noqa: E402
+configs = ((1, 1), (2, 1), (4, 1), (8, 1), (16, 1), (1, 4), (1, 8), (1, 16), (1, 32), (2, 8), (2, 16), (4, 8), (4, 16))
+if os.environ.get("SERVING_CONFIGS"):          # e.g. "1x32,2x16": threads x batch
+    configs = tuple(tuple(int(v) for v in c.split("x")) for c in os.environ["SERVING_CONFIGS"].split(","))
+for nthreads, batch in configs:
     per = max(2 * batch, 256 // nthreads)
     r = subprocess.run([str(exe), str(out / "job.bin"), str(flags), str(niter), str(nthreads), str(per), str(batch)],
                        capture_output=True, text=True)
