@@ -806,32 +806,42 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
       host_pieces(jobs[which[g]], ci, 0, jobs[which[g]]->hblk[ci], cj[g].coef_off[ci], back);
   }
   HIP_TRY(down.finish(coef.p, back, s));
+  // replacement arrays: first every transfer is completed (nothing handed out yet, so an error on the
+  // way leaves no job half-updated), then ownership moves to the jobs
+  struct UpArrays {
+    std::vector<int16_t*> p;
+    ~UpArrays() { for (int16_t* q : p) if (q) free(q); }                    // (only malloc'ed ones are kept here)
+  } ups;
+  ups.p.assign((size_t)G * 2, nullptr);
   for (int g = 0; g < G; ++g) {
-    qs_hip_job* job = jobs[which[g]];
+    if (!cj[g].upsample) continue;
     const bool bad = (hst[g * 3] | hst[g * 3 + 1] | hst[g * 3 + 2]) != 0;
-    if (cj[g].upsample) {
-      int16_t* up[2] = {nullptr, nullptr};
-      bool ok = !bad;
-      for (int k = 0; k < 2; ++k) {
-        Download& D = *down_up_of[(size_t)g * 2 + k];
-        const char* src = upc.as<char>() + cj[g].upc_off[k];
-        if (D.staged) {
-          // the replacement array IS the pinned download buffer: it changes owner (qs_hip_free gives it back)
-          HIP_TRY(D.finish(src, std::vector<Piece>{}, s));
-          if (ok) up[k] = static_cast<int16_t*>(pinned_handout(D.stage));
-        } else if (ok) {
-          up[k] = static_cast<int16_t*>(malloc(cj[g].ubytes));
-          if (!up[k]) { qs_hip_free(up[0]); return qs_fail(QS_HIP_ENOMEM, "out of host memory"); }
-          HIP_TRY(D.finish(src, std::vector<Piece>{{up[k], 0, cj[g].ubytes}}, s));
-        }
-      }
-      if (ok) {                                              // reference :2836-2849
-        job->coef_up[0] = up[0]; job->coef_up[1] = up[1];
-        job->up_wblk = job->wblk[0]; job->up_hblk = job->hblk[0];
-        job->out_hsamp0 = job->out_vsamp0 = 1;
+    for (int k = 0; k < 2; ++k) {
+      Download& D = *down_up_of[(size_t)g * 2 + k];
+      const char* src = upc.as<char>() + cj[g].upc_off[k];
+      if (D.staged) {
+        HIP_TRY(D.finish(src, std::vector<Piece>{}, s));                    // (waits for its chunks)
+      } else if (!bad) {
+        int16_t* q = static_cast<int16_t*>(malloc(cj[g].ubytes));
+        if (!q) return qs_fail(QS_HIP_ENOMEM, "out of host memory");
+        ups.p[(size_t)g * 2 + k] = q;
+        HIP_TRY(D.finish(src, std::vector<Piece>{{q, 0, cj[g].ubytes}}, s));
       }
     }
-    if (bad) continue;
+  }
+  for (int g = 0; g < G; ++g) {
+    qs_hip_job* job = jobs[which[g]];
+    if (hst[g * 3] | hst[g * 3 + 1] | hst[g * 3 + 2]) continue;
+    if (cj[g].upsample) {                                    // reference :2836-2849
+      for (int k = 0; k < 2; ++k) {
+        Download& D = *down_up_of[(size_t)g * 2 + k];
+        // a staged array IS the pinned download buffer: it changes owner (qs_hip_free gives it back to the pool)
+        job->coef_up[k] = D.staged ? static_cast<int16_t*>(pinned_handout(D.stage)) : ups.p[(size_t)g * 2 + k];
+        ups.p[(size_t)g * 2 + k] = nullptr;
+      }
+      job->up_wblk = job->wblk[0]; job->up_hblk = job->hblk[0];
+      job->out_hsamp0 = job->out_vsamp0 = 1;
+    }
     for (int ci = 0; ci < 3; ++ci)                           // reference :2851-2859
       for (int i = 0; i < 64; ++i) job->quant[ci][i] = 1;
     results[which[g]] = 0;
