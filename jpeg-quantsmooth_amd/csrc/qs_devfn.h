@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "qs_device.h"
 
 // float -> int32 the way x86-64 cvttss2si does it (the reference's
 // `int range = roundf(a2)`): NaN / out of range => INT_MIN.
@@ -29,3 +30,14 @@ __device__ __forceinline__ void interval(int c, int div, int x1, int sh, int& or
   lo = a - (a > 0 ? d1 : d0);
 }
 
+
+// index of the plane that owns 64-block group `w` of a plane-set launch
+// (binary search over the prefix array; everything here is wave-uniform)
+__device__ __forceinline__ int qs_set_find(const QsPlaneSet& set, int w) {
+  int lo = 0, hi = set.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (set.wave0[mid] <= w) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}

@@ -67,6 +67,11 @@ enum {
   QS_PLANE_REP_TOP = 2,    // pass A: the y = -1 apron row is a replica of row 0 (image edge) ...
   QS_PLANE_REP_BOT = 4     // ... / the y = h apron row of row h-1; clear = halo row owned by the neighbouring band
 };
+// one more device pointer per plane of a set, for the stages that read a second plane
+// (JOINT_YUV: the low-res luma plane the chroma plane is predicted from)
+struct QsPlaneAux {
+  const uint8_t* p[QS_MAX_PLANES];
+};
 struct QsPlaneSet {
   int32_t n, pad;
   // wave0[i] = index of the first 64-block group of plane i in the launch;

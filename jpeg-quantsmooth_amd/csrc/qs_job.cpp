@@ -737,15 +737,15 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
   // ---- chroma.  A job that is upsampled afterwards takes one more refresh pass (and its clamp moves
   // behind it); jobs of both kinds may share a group, so the extra pass runs on a set of its own.
   make_set(set, 1, 3);
+  QsPlaneAux lowres;
+  memset(&lowres, 0, sizeof lowres);
+  for (int g = 0; g < G; ++g) lowres.p[2 * g] = lowres.p[2 * g + 1] = lowres_of(g);
   bool any_up = false, all_up = true;
   for (int g = 0; g < G; ++g) { any_up |= cj[g].upsample; all_up &= cj[g].upsample; }
   for (int it = 0; it < niter; ++it) {
     qs_launch_idct_set(set, it == 0, s);
     if (joint)                                               // JOINT_YUV acts through the low-res luma plane (reference :2636)
-      for (int g = 0; g < G; ++g)
-        for (int ci = 1; ci < 3; ++ci)
-          qs_launch_joint(cst.as<QsConsts>() + cj[g].cst[ci], coef_of(g, ci), plane_of(g, ci), lowres_of(g),
-                          jobs[which[g]]->wblk[ci], jobs[which[g]]->hblk[ci], 0, 0, s);
+      qs_launch_joint_set(set, lowres, 0, 0, s);
     qs_launch_smooth_set(set, diag, it == niter - 1 && !any_up, s);
   }
   if (any_up) {

@@ -318,16 +318,7 @@ qs_idct_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coe
   idct_block_to_plane(cst, coef, plane, wblk, hblk, pitch, first, rep_top, rep_bot, status, blk);
 }
 
-// index of the plane that owns 64-block group `w` of a plane-set launch
-// (binary search over the prefix array; everything here is wave-uniform)
-__device__ __forceinline__ int qs_set_find(const QsPlaneSet& set, int w) {
-  int lo = 0, hi = set.n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (set.wave0[mid] <= w) lo = mid; else hi = mid - 1;
-  }
-  return lo;
-}
+#include "qs_devfn.h"
 
 // pass A over a set of planes (whole planes, or bands whose halo-side apron rows are left alone)
 __global__ void __launch_bounds__(256)
@@ -346,7 +337,6 @@ qs_idct_set_kernel(const QsPlaneSet set, int first) {
 // Kernel B: the recovery loop.  Reference quantsmooth.h:1396-1565 (main loop),
 // :1566-1568 + :1823-1848 (rebalance), :2668-2689 (final clamp, optional).
 
-#include "qs_devfn.h"
 
 // 16-bit views of the dword columns.  may_alias: these accesses overlap the
 // 32-bit accesses used for staging and for the IDCT refresh, and the compiler

@@ -171,13 +171,9 @@ __device__ __forceinline__ float regress(const int (&a0)[10], const int (&a1)[10
 // --------------------------------------------------------------------------
 // JOINT_YUV predictor: one chroma block per lane.  planeC = this component's
 // plane (pass A of this iteration), planeL = low-res luma; same geometry.
-__global__ void __launch_bounds__(256)
-qs_joint_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
-                const uint8_t* __restrict__ planeC, const uint8_t* __restrict__ planeL,
-                int wblk, int hblk, int pitch, int do_rebalance, int final_clamp) {
-  const int nblk = wblk * hblk;
-  const int blk = blockIdx.x * 256 + threadIdx.x;
-  if (blk >= nblk) return;
+__device__ __forceinline__ void joint_block(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
+                                            const uint8_t* __restrict__ planeC, const uint8_t* __restrict__ planeL,
+                                            int wblk, int pitch, int blk, int do_rebalance, int final_clamp) {
   const int by = blk / wblk, bx = blk - by * wblk;
   const size_t org = (size_t)(by * 8 + 1) * pitch + QS_APRON_X + bx * 8;
 
@@ -209,6 +205,30 @@ qs_joint_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
     for (int n = 0; n < 64; ++n) c[n] = min(max(c[n], -1023), 1023);
   }
   store_block(coef, blk, c);
+}
+
+__global__ void __launch_bounds__(256)
+qs_joint_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
+                const uint8_t* __restrict__ planeC, const uint8_t* __restrict__ planeL,
+                int wblk, int hblk, int pitch, int do_rebalance, int final_clamp) {
+  const int blk = blockIdx.x * 256 + threadIdx.x;
+  if (blk >= wblk * hblk) return;
+  joint_block(cst, coef, planeC, planeL, wblk, pitch, blk, do_rebalance, final_clamp);
+}
+
+// the same over a set of chroma planes (the coupled jobs of a batch, qs_job.cpp: run_coupled): one
+// launch instead of one per plane -- a full-HD chroma plane is 128 waves, alone it runs at the
+// latency of a single wave
+__global__ void __launch_bounds__(256)
+qs_joint_set_kernel(const QsPlaneSet set, const QsPlaneAux lowres, int do_rebalance, int final_clamp) {
+  const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (w >= set.wave0[set.n]) return;
+  const int i = qs_set_find(set, w);
+  const QsPlaneRef& r = set.ref[i];
+  const int blk = (w - set.wave0[i]) * 64 + (threadIdx.x & 63);
+  if (blk >= r.wblk * r.hblk) return;
+  joint_block(r.cst, r.coef, r.plane, lowres.p[i], r.wblk, r.pitch, blk,
+              do_rebalance && (r.mode & QS_PLANE_REBALANCE), final_clamp);
 }
 
 // --------------------------------------------------------------------------
@@ -371,6 +391,12 @@ void qs_launch_joint(const QsConsts* cst, int16_t* coef, const uint8_t* planeC, 
   const int nblk = wblk * hblk;
   hipLaunchKernelGGL(qs_joint_kernel, dim3((nblk + 255) / 256), dim3(256), 0, s,
                      cst, coef, planeC, planeL, wblk, hblk, qs_plane_pitch(wblk), do_rebalance, final_clamp);
+}
+
+void qs_launch_joint_set(const QsPlaneSet& set, const QsPlaneAux& lowres, int do_rebalance, int final_clamp, hipStream_t s) {
+  const int nw = set.wave0[set.n];
+  if (nw <= 0) return;
+  hipLaunchKernelGGL(qs_joint_set_kernel, dim3((nw + 3) / 4), dim3(256), 0, s, set, lowres, do_rebalance, final_clamp);
 }
 
 void qs_launch_lowq(const QsConsts* cst, int16_t* coef, const uint8_t* plane, int wblk, int hblk,

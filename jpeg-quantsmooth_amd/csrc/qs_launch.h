@@ -18,6 +18,9 @@ void qs_launch_dequant(const QsConsts* cst, int16_t* coef, size_t nblk, hipStrea
 // qs_kernels_aux.hip: cross-component (JOINT_YUV / UPSAMPLE_UV) and LOW_QUALITY stages
 void qs_launch_joint(const QsConsts* cst, int16_t* coef, const uint8_t* planeC, const uint8_t* planeL,
                      int wblk, int hblk, int do_rebalance, int final_clamp, hipStream_t s);
+// ... over the chroma planes of a set; lowres.p[i] = the low-res luma plane of set.ref[i];
+// do_rebalance applies to the planes whose mode carries QS_PLANE_REBALANCE
+void qs_launch_joint_set(const QsPlaneSet& set, const QsPlaneAux& lowres, int do_rebalance, int final_clamp, hipStream_t s);
 void qs_launch_lowq(const QsConsts* cst, int16_t* coef, const uint8_t* plane, int wblk, int hblk,
                     int do_rebalance, int final_clamp, float c1, hipStream_t s);
 void qs_launch_downsample(const uint8_t* Y, int ywblk, int yhblk, uint8_t* L, int lwblk, int lhblk,
