@@ -9,6 +9,7 @@
 // library, however many translation units include this header.
 #pragma once
 #include <new>
+#include <string>
 #include <mutex>
 #include <vector>
 #include <deque>
@@ -46,6 +47,24 @@ inline size_t round_size(size_t n) {               // size classes: powers of tw
   return c;
 }
 
+// Test hook (tests/test_gpu_faults.py): QS_HIP_TEST_FAIL_ALLOC=N makes the N-th device allocation
+// request after the variable was set or changed fail once with hipErrorOutOfMemory, so that the error
+// paths of the job layer (drain guards, pool returns, fall-backs, compute slots) can be exercised.
+inline bool test_fail_alloc() {
+  static std::atomic<bool> armed{false};
+  static std::mutex mu;
+  static std::string seen;
+  static long countdown = 0;
+  const char* v = getenv("QS_HIP_TEST_FAIL_ALLOC");
+  if (!v) {                                           // (the production path: one getenv per buffer request)
+    if (armed.load(std::memory_order_relaxed)) { std::lock_guard<std::mutex> lk(mu); seen.clear(); armed = false; }
+    return false;
+  }
+  std::lock_guard<std::mutex> lk(mu);
+  if (seen != v) { seen = v; countdown = atol(v); armed = true; }
+  return countdown > 0 && --countdown == 0;
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t n = 0;
@@ -56,6 +75,7 @@ struct DevBuf {
   ~DevBuf() { release(); }
   hipError_t alloc(size_t bytes) {
     release();
+    if (test_fail_alloc()) return hipErrorOutOfMemory;
     const size_t want = round_size(bytes);
     dev = current_device();                        // allocations belong to the caller's current device
     {

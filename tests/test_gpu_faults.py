@@ -1,0 +1,111 @@
+"""Error paths of the job layer under injected device-allocation failures (QS_HIP_TEST_FAIL_ALLOC=N: the
+N-th device buffer request fails once, csrc/qs_xfer.h).  Whatever route a job takes -- plane sets, the
+general per-component route, coupled groups from worker threads, bands over logical devices -- a failed
+allocation must surface as an error code (or as the reference's own fall-back: a component whose pixel
+plane cannot be allocated is dequantised only, reference quantsmooth.h:2551-2566), never as a crash, a
+hang or a wrong result, and the library must work normally afterwards (streams drained before pooled
+buffers are reused, compute slots released, worker threads joined)."""
+import numpy as np
+import pytest
+
+from helpers import assert_same_result
+
+pytestmark = pytest.mark.gpu
+
+
+def _dequant_only(coef, quant):
+    q = np.asarray(quant, dtype=np.int32).reshape(1, 1, 64)
+    return np.clip(coef.astype(np.int32) * q, -1023, 1023).astype(np.int16)
+
+
+def _colour_jobs(synth, n, seed0):
+    jobs = []
+    for k in range(n):
+        w, h = 96 + 16 * (k % 3), 64 + 8 * (k % 4)
+        j = synth.synth_ycc(w, h, 2, 2, quality=40 + 10 * (k % 3), seed=seed0 + k)
+        jobs.append(dict(coefs=j["coefs"], quants=j["quants"], hsamp=j["hsamp"], vsamp=j["vsamp"],
+                         colorspace=3, image_size=(w, h)))
+    return jobs
+
+
+def _want(oracle, j, flags, niter):
+    kw = {n: j[n] for n in ("hsamp", "vsamp", "colorspace", "image_size") if n in j}
+    return oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+
+
+@pytest.mark.parametrize("nth", [1, 2, 3, 4, 5, 7])
+def test_single_job_allocation_failure(gpu, oracle, synth, monkeypatch, nth):
+    """one gray job (plane-set route) and one 4:2:0 --quality 6 job (general route)"""
+    coef, quant = synth.synth_gray(200, 136, 50, seed=3)
+    gray = dict(coefs=[coef], quants=[quant])
+    colour = _colour_jobs(synth, 1, 40)[0]
+    for job, flags in ((gray, 0), (colour, 7)):
+        want = _want(oracle, job, flags, 2)
+        kw = {n: job[n] for n in ("hsamp", "vsamp", "colorspace", "image_size") if n in job}
+        monkeypatch.setenv("QS_HIP_TEST_FAIL_ALLOC", f"{nth}")
+        try:
+            got = gpu.do_quantsmooth(job["coefs"], job["quants"], flags, 2, **kw)
+        except Exception:
+            got = None                                            # the failure was reported: fine
+        finally:
+            monkeypatch.delenv("QS_HIP_TEST_FAIL_ALLOC")
+        if nth == 1 and flags == 0:
+            assert got is None, "the very first allocation of the plane-set route failed: the call must say so"
+        if got is not None and flags == 0:
+            # no exception: either the fault was never reached, or the reference's fall-back applied
+            assert got["ret"] == 0
+            ok = np.array_equal(got["coefs"][0], want["coefs"][0]) or \
+                np.array_equal(got["coefs"][0], _dequant_only(coef, quant))
+            assert ok, f"nth={nth}: neither the recovered nor the dequantised-only plane"
+        # and the library is healthy afterwards
+        again = gpu.do_quantsmooth(job["coefs"], job["quants"], flags, 2, **kw)
+        assert_same_result(again, want, f"after an injected failure (nth={nth}, flags={flags})")
+
+
+@pytest.mark.parametrize("nth", [1, 2, 3, 5, 6, 9, 12])
+@pytest.mark.parametrize("flags", [0, 7])
+def test_batch_allocation_failure(gpu, oracle, synth, monkeypatch, nth, flags):
+    """batches: plane-set groups (flags 0) and coupled groups on worker threads (flags 7)"""
+    jobs = _colour_jobs(synth, 7, 60)
+    monkeypatch.setenv("QS_HIP_COUPLE_BLOCKS", "1500")            # several coupled groups -> several worker threads
+    monkeypatch.setenv("QS_HIP_TEST_FAIL_ALLOC", f"{nth}")
+    try:
+        got = gpu.do_quantsmooth_batch(jobs, flags, 2)
+    except Exception:
+        got = None
+    finally:
+        monkeypatch.delenv("QS_HIP_TEST_FAIL_ALLOC")
+    if nth == 1:
+        assert got is None or any(a["ret"] < 0 for a in got), "an allocation failed: somebody must report it"
+    if got is not None:
+        for k, (j, a) in enumerate(zip(jobs, got)):
+            if a["ret"] < 0:
+                continue                                          # this job reported the failure
+            if flags == 0:                                        # (a coupled job may have taken the dequantise-only fall-back)
+                assert_same_result(a, _want(oracle, j, flags, 2), f"nth={nth} job {k}")
+    again = gpu.do_quantsmooth_batch(jobs, flags, 2)
+    for k, (j, a) in enumerate(zip(jobs, again)):
+        assert_same_result(a, _want(oracle, j, flags, 2), f"after an injected failure (nth={nth}) job {k}")
+
+
+@pytest.mark.parametrize("nth", [1, 2, 4, 6, 9])
+def test_sharded_allocation_failure(gpu, oracle, synth, monkeypatch, nth):
+    """bands over two logical devices on one GPU (C-side sharding): set route and coupled-colour route"""
+    coef, quant = synth.synth_gray(264, 328, 50, seed=4)
+    gray = dict(coefs=[coef], quants=[quant])
+    colour = _colour_jobs(synth, 1, 80)[0]
+    for job, flags in ((gray, 1), (colour, 7)):
+        kw = {n: job[n] for n in ("hsamp", "vsamp", "colorspace", "image_size") if n in job}
+        want = _want(oracle, job, flags, 2)
+        monkeypatch.setenv("QS_HIP_TEST_FAIL_ALLOC", f"{nth}")
+        raised = False
+        try:
+            gpu.do_quantsmooth(job["coefs"], job["quants"], flags, 2, devices=[0, 0], **kw)
+        except Exception:
+            raised = True
+        finally:
+            monkeypatch.delenv("QS_HIP_TEST_FAIL_ALLOC")
+        if nth == 1:
+            assert raised, "the first allocation of a band failed: the call must say so"
+        again = gpu.do_quantsmooth(job["coefs"], job["quants"], flags, 2, devices=[0, 0], **kw)
+        assert_same_result(again, want, f"after an injected failure (nth={nth}, flags={flags})")
