@@ -50,20 +50,28 @@ inline size_t round_size(size_t n) {               // size classes: powers of tw
 // Test hook (tests/test_gpu_faults.py): QS_HIP_TEST_FAIL_ALLOC=N makes the N-th device allocation
 // request after the variable was set or changed fail once with hipErrorOutOfMemory, so that the error
 // paths of the job layer (drain guards, pool returns, fall-backs, compute slots) can be exercised.
-inline bool test_fail_alloc() {
-  static std::atomic<bool> armed{false};
-  static std::mutex mu;
-  static std::string seen;
-  static long countdown = 0;
-  const char* v = getenv("QS_HIP_TEST_FAIL_ALLOC");
-  if (!v) {                                           // (the production path: one getenv per buffer request)
-    if (armed.load(std::memory_order_relaxed)) { std::lock_guard<std::mutex> lk(mu); seen.clear(); armed = false; }
-    return false;
+// QS_HIP_TEST_FAIL_PINNED=N does the same for pinned host buffers (the transfers then take their
+// pageable fall-backs, or the call reports QS_HIP_ENOMEM where a pinned block is indispensable).
+struct TestFault {
+  const char* name;
+  std::atomic<bool> armed{false};
+  std::mutex mu;
+  std::string seen;
+  long countdown = 0;
+  explicit TestFault(const char* n) : name(n) {}
+  bool fire() {
+    const char* v = getenv(name);
+    if (!v) {                                         // (the production path: one getenv per buffer request)
+      if (armed.load(std::memory_order_relaxed)) { std::lock_guard<std::mutex> lk(mu); seen.clear(); armed = false; }
+      return false;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    if (seen != v) { seen = v; countdown = atol(v); armed = true; }
+    return countdown > 0 && --countdown == 0;
   }
-  std::lock_guard<std::mutex> lk(mu);
-  if (seen != v) { seen = v; countdown = atol(v); armed = true; }
-  return countdown > 0 && --countdown == 0;
-}
+};
+inline bool test_fail_alloc() { static TestFault f("QS_HIP_TEST_FAIL_ALLOC"); return f.fire(); }
+inline bool test_fail_pinned() { static TestFault f("QS_HIP_TEST_FAIL_PINNED"); return f.fire(); }
 
 struct DevBuf {
   void* p = nullptr;
@@ -125,6 +133,7 @@ struct PinnedBuf {
   ~PinnedBuf() { release(); }
   static std::vector<CacheEntry>& pool() { static std::vector<CacheEntry> v; return v; }   // (inline function: one per library)
   bool alloc(size_t bytes) {
+    if (test_fail_pinned()) return false;
     const size_t want = round_size(bytes);
     {
       std::lock_guard<std::mutex> lk(g_cache_mu);

@@ -1,5 +1,5 @@
-"""Error paths of the job layer under injected device-allocation failures (QS_HIP_TEST_FAIL_ALLOC=N: the
-N-th device buffer request fails once, csrc/qs_xfer.h).  Whatever route a job takes -- plane sets, the
+"""Error paths of the job layer under injected allocation failures (QS_HIP_TEST_FAIL_ALLOC=N: the N-th device
+buffer request fails once; QS_HIP_TEST_FAIL_PINNED=N: the N-th pinned host buffer request, csrc/qs_xfer.h).  Whatever route a job takes -- plane sets, the
 general per-component route, coupled groups from worker threads, bands over logical devices -- a failed
 allocation must surface as an error code (or as the reference's own fall-back: a component whose pixel
 plane cannot be allocated is dequantised only, reference quantsmooth.h:2551-2566), never as a crash, a
@@ -109,3 +109,38 @@ def test_sharded_allocation_failure(gpu, oracle, synth, monkeypatch, nth):
             assert raised, "the first allocation of a band failed: the call must say so"
         again = gpu.do_quantsmooth(job["coefs"], job["quants"], flags, 2, devices=[0, 0], **kw)
         assert_same_result(again, want, f"after an injected failure (nth={nth}, flags={flags})")
+
+
+@pytest.mark.parametrize("nth", [1, 2, 3, 4, 6, 8])
+@pytest.mark.parametrize("flags", [1, 7])
+def test_pinned_allocation_failure(gpu, oracle, synth, monkeypatch, nth, flags):
+    """pinned staging buffers: without one a transfer takes its pageable fall-back (the result is still
+    exact) or the call reports the failure; planes large enough for the staged paths (> 1 MiB)"""
+    big = synth.synth_ycc(1024, 768, 2, 2, quality=50, seed=7)
+    job = dict(coefs=big["coefs"], quants=big["quants"], hsamp=big["hsamp"], vsamp=big["vsamp"],
+               colorspace=3, image_size=(1024, 768))
+    small = _colour_jobs(synth, 5, 90)
+    kw = {n: job[n] for n in ("hsamp", "vsamp", "colorspace", "image_size")}
+    want = _want(oracle, job, flags, 1)
+    monkeypatch.setenv("QS_HIP_TEST_FAIL_PINNED", f"{nth}")
+    try:
+        got = gpu.do_quantsmooth(job["coefs"], job["quants"], flags, 1, **kw)
+    except Exception:
+        got = None
+    finally:
+        monkeypatch.delenv("QS_HIP_TEST_FAIL_PINNED")
+    if got is not None:
+        assert_same_result(got, want, f"single job with a failed pinned allocation (nth={nth}, flags={flags})")
+    monkeypatch.setenv("QS_HIP_TEST_FAIL_PINNED", f"{nth}")
+    try:
+        res = gpu.do_quantsmooth_batch([job] + small, flags, 1)
+    except Exception:
+        res = None
+    finally:
+        monkeypatch.delenv("QS_HIP_TEST_FAIL_PINNED")
+    if res is not None:
+        for k, (j, a) in enumerate(zip([job] + small, res)):
+            if a["ret"] >= 0:
+                assert_same_result(a, _want(oracle, j, flags, 1), f"batch job {k} (nth={nth}, flags={flags})")
+    again = gpu.do_quantsmooth(job["coefs"], job["quants"], flags, 1, **kw)
+    assert_same_result(again, want, f"after an injected pinned failure (nth={nth}, flags={flags})")
