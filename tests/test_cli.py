@@ -112,6 +112,36 @@ def test_cli_stdin_stdout_and_inplace(gpu, tmp_path):
     assert r.returncode == 0 and f.read_bytes() == (GOLD / "gray64.q4.ref.jpg").read_bytes()
 
 
+@pytest.fixture(scope="module")
+def gray8192_jpeg(tmp_path_factory, pkg):
+    """BASELINE.md section 3's input for configs[2]: the synthetic 8192 x 8192 luma image of SURVEY.md 8d as a
+    real libjpeg-encoded file (quality 50, baseline Huffman)"""
+    from PIL import Image
+    Image.MAX_IMAGE_PIXELS = None
+    path = tmp_path_factory.mktemp("big") / "gray_8192.jpg"
+    Image.fromarray(pkg.synth.synth_pixels(8192, 8192), "L").save(path, quality=50)
+    return path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("quality", [3, 4])
+def test_cli_8192_gray_matches_reference_cli_bytes(gpu, tmp_path, gray8192_jpeg, quality):
+    """end to end at the headline size: JPEG in -> entropy decode -> do_quantsmooth on the GPU -> entropy encode,
+    byte for byte what the reference's own CLI (scalar build, OpenMP) writes for the same file -- i.e. all
+    1,048,576 blocks equal (reference quantsmooth.c:548-596, quantsmooth.h:1517-1549)"""
+    _need_cli()
+    ref_cli = ROOT / "oracle" / "_ref" / "jpegqs_ref_none"
+    if not ref_cli.exists():
+        pytest.skip("oracle/_ref/jpegqs_ref_none did not travel with the tree")
+    ours, ref = tmp_path / "ours.jpg", tmp_path / "ref.jpg"
+    r = subprocess.run([str(CLI), "-q", str(quality), "-i", "8", str(gray8192_jpeg), str(ours)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r2 = subprocess.run([str(ref_cli), "-q", str(quality), "-i", "0", str(gray8192_jpeg), str(ref)], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    a, b = ours.read_bytes(), ref.read_bytes()
+    assert len(a) > 1 << 20 and a == b, f"outputs differ ({len(a)} vs {len(b)} bytes)"
+
+
 # ---- decode-mode API (jpegqs_start_decompress / jpegqs_finish_decompress) -------
 DECODE = ROOT / "oracle" / "decode_hip"   # oracle/decode_demo.c linked against the product's libjpegqs.so
 

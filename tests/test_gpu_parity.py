@@ -212,34 +212,6 @@ def test_gpu_iteration_limits(gpu, oracle, synth):
     assert_same_result(a, b, "niter=0 upsample")
 
 
-def test_gpu_max_plane_16384(gpu, synth):
-    """BASELINE config 3 size on one GPU: 16384 x 16384 luma (4.2 M blocks, 512 MiB
-    of coefficients): runs, stays inside the quantisation intervals, and a band
-    equals the same band computed from a cropped plane (locality)"""
-    import torch
-    import bench
-    dev = torch.device("cuda:0")
-    import jpegqs_pkg
-    pkg = jpegqs_pkg.load()
-    coef, quant = bench.synth_input_gpu(torch, pkg, 16384, 50, dev)
-    hb, wb = coef.shape[:2]
-    from jpeg_quantsmooth_amd import bands
-    eng = bands.HipBandEngine(gpu, torch, coef.clone(), quant, 0)
-    topo = bands.BandTopology(0, 1, 0, hb)
-    bands.run_band(eng, topo, 2, lambda: None)
-    torch.cuda.synchronize()
-    assert not eng.bad_coef()
-    sub = bands.HipBandEngine(gpu, torch, coef[1000:1016].clone(), quant, 0)
-    bands.run_band(sub, bands.BandTopology(0, 1, 0, 16), 2, lambda: None)
-    torch.cuda.synchronize()
-    assert torch.equal(eng.coef[1003:1013], sub.coef[3:13])
-    q = torch.from_numpy(quant.astype(np.int32)).to(dev)
-    deq = coef.to(torch.int32) * q
-    g = eng.coef.to(torch.int32)
-    assert int(g.abs().max()) <= 1023
-    assert bool((((g - deq).abs() <= q // 2) | (g.abs() == 1023)).all())
-
-
 def test_gpu_job_layer_is_thread_safe(gpu, oracle, synth):
     """concurrent do_quantsmooth() calls from host threads (a serving process):
     each call leases its own streams and pooled device buffers; results stay bit-exact"""
@@ -484,32 +456,6 @@ for flags, niter in ((0, 3), (1, 2)):
 print("ok")
 '''
     assert "ok" in _run_py(code, _BAND_ENV)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("quality", [3, 4])
-def test_gpu_8192_headline_plane_exact_bands(gpu, pkg, oracle, big_plane, quality):
-    """The configuration the bar is quoted on (BASELINE metric: 8192x8192 luma, q=3 niter=3;
-    configs[2]: q=4), through the device-resident plane layer exactly as bench.py drives it:
-    16 block rows at the top, in the middle and at the bottom (all 1024 block columns, so the
-    left/right image edges too) must equal the oracle bit for bit; reference
-    quantsmooth.h:1517-1549 is the summation order that decides it"""
-    import torch
-    from jpeg_quantsmooth_amd import bands
-    from oracle.oracle import RowSource, verify_bands
-    coef, quant = big_plane
-    flags = pkg.flags_for_quality(quality)
-    dev = torch.device("cuda:0")
-    d_coef = torch.from_numpy(coef).to(dev)
-    eng = bands.HipBandEngine(gpu, torch, d_coef, quant, flags, luma=1, device=dev)
-    for it in range(3):
-        eng.idct(it == 0, 1, 1)
-        eng.smooth(it == 2)
-    torch.cuda.synchronize()
-    assert not eng.bad_coef()
-    detail = verify_bands(oracle, RowSource(coef), quant, flags, 3, RowSource(d_coef), rows=16)
-    assert [d["where"] for d in detail] == ["top", "middle", "bottom"]
-    assert all(d["bad_blocks"] == 0 for d in detail), detail
 
 
 @pytest.mark.gpu

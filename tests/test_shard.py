@@ -87,21 +87,6 @@ def test_sharded_route_taken_transparently(gpu):
     assert "400 trials, 959 jobs" in out and " 0 failures" in out
 
 
-@pytest.mark.gpu
-def test_sharded_8192_equals_unsharded_gpu_and_oracle_bands(gpu, oracle, big_plane):
-    """BASELINE configs[2]/[3] scale: an 8192x8192 luma plane over 8 bands equals the one-device
-    result everywhere, and both equal the oracle on 16 block rows at the top, middle and bottom"""
-    from oracle.oracle import RowSource, verify_bands
-    coef, quant = big_plane
-    for flags in (0, 1):
-        one = gpu.do_quantsmooth([coef], [quant], flags, 3)
-        many = gpu.do_quantsmooth([coef], [quant], flags, 3, devices=[0] * 8)
-        assert one["ret"] == many["ret"] == 0
-        assert np.array_equal(one["coefs"][0], many["coefs"][0]), f"flags={flags}: sharded != unsharded"
-        for v in verify_bands(oracle, RowSource(coef), quant, flags, 3, RowSource(many["coefs"][0])):
-            assert v["bad_blocks"] == 0, (flags, v)
-
-
 def test_rows_entry_point_argument_checks(hip):
     import ctypes as C
     job, _ = hip._make_job([np.zeros((2, 2, 64), np.int16)], [np.full(64, 4, np.uint16)])
