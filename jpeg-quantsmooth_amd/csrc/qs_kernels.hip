@@ -467,6 +467,12 @@ __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >
 // tail-round wave priority (see qs_smooth_kernel.inc); workgroups the chip holds at
 // once = 256 CUs x 3 (the kernel's VGPR budget leaves room for 3 waves per SIMD and a
 // workgroup puts one wave on each of a CU's four SIMDs)
+// QS_REFRESH_SKIP=1: the refresh IDCT at an anti-diagonal start is skipped when no block of the
+// wave changed a coefficient since the previous refresh (the reference's need_refresh,
+// quantsmooth.h:1407-1409, made wave-uniform); exact by construction.
+#ifndef QS_REFRESH_SKIP
+#define QS_REFRESH_SKIP 1
+#endif
 #ifndef QS_TAIL_PRIO
 #define QS_TAIL_PRIO 1
 #endif

@@ -1,0 +1,77 @@
+// cold_phases.cpp -- where does a FRESH process spend its time before and inside the first
+// do_quantsmooth?  (the drop-in CLI is start-up bound.)
+// Every phase is timed on the host clock in one fresh process; run it several times.
+//   hipcc -O2 -o cold_phases tools/cold_phases.cpp -Ijpeg-quantsmooth_amd/../include -Ljpeg-quantsmooth_amd -ljpegqs_hip -Wl,-rpath,$PWD/jpeg-quantsmooth_amd
+//   ./cold_phases [width height [ncomp]]        (default 1920 1080 3 = a full-HD 4:2:0 frame, --quality 3)
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../include/jpegqs_hip.h"
+
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+#define PHASE(name, stmt) do { const double t0_ = now_ms(); stmt; printf("  %-46s %9.2f ms\n", name, now_ms() - t0_); } while (0)
+
+static void fill(std::vector<int16_t>& c, unsigned seed) {
+  for (size_t b = 0; b < c.size() / 64; ++b) {
+    int16_t* p = &c[b * 64];
+    memset(p, 0, 128);
+    seed = seed * 1664525u + 1013904223u; p[0] = (int16_t)((int)(seed >> 24) % 40 - 20);
+    seed = seed * 1664525u + 1013904223u; p[1] = (int16_t)((int)(seed >> 24) % 7 - 3);
+    seed = seed * 1664525u + 1013904223u; p[8] = (int16_t)((int)(seed >> 24) % 7 - 3);
+    seed = seed * 1664525u + 1013904223u; p[9] = (int16_t)((int)(seed >> 24) % 3 - 1);
+  }
+}
+
+int main(int argc, char** argv) {
+  const int w = argc > 2 ? atoi(argv[1]) : 1920, h = argc > 2 ? atoi(argv[2]) : 1080, nc = argc > 3 ? atoi(argv[3]) : 3;
+  const int skip_runtime = getenv("COLD_SKIP_RUNTIME") != nullptr;   // let the library make the first HIP call itself
+  const double t_main = now_ms();
+  printf("fresh process, %dx%d, %d component(s)%s\n", w, h, nc, skip_runtime ? " (library makes the first HIP call)" : "");
+  if (!skip_runtime) {
+    int n = 0;
+    PHASE("hipInit(0)", (void)hipInit(0));
+    PHASE("hipGetDeviceCount", (void)hipGetDeviceCount(&n));
+    PHASE("hipSetDevice(0) + hipFree(0) (context)", { (void)hipSetDevice(0); (void)hipFree(nullptr); });
+    hipStream_t s[3];
+    PHASE("3 x hipStreamCreateWithFlags", for (int i = 0; i < 3; ++i) (void)hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
+    void* hp = nullptr; void* dp = nullptr;
+    PHASE("hipHostMalloc 8 MiB (portable)", (void)hipHostMalloc(&hp, 8 << 20, hipHostMallocPortable));
+    PHASE("hipHostMalloc 8 MiB again", { void* q = nullptr; (void)hipHostMalloc(&q, 8 << 20, hipHostMallocPortable); (void)hipHostFree(q); });
+    PHASE("hipMalloc 8 MiB", (void)hipMalloc(&dp, 8 << 20));
+    PHASE("hipMalloc 128 MiB", { void* q = nullptr; (void)hipMalloc(&q, 128 << 20); (void)hipFree(q); });
+    PHASE("hipMemcpy H2D 8 MiB pinned", (void)hipMemcpy(dp, hp, 8 << 20, hipMemcpyHostToDevice));
+    (void)hipHostFree(hp); (void)hipFree(dp);
+    for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(s[i]);
+  }
+  qs_hip_job job;
+  memset(&job, 0, sizeof job);
+  job.ncomp = nc; job.colorspace = nc == 3 ? 3 : 1; job.image_width = w; job.image_height = h;
+  std::vector<std::vector<int16_t>> coef(nc);
+  for (int ci = 0; ci < nc; ++ci) {
+    const int sub = (nc == 3 && ci) ? 2 : 1;
+    job.hsamp[ci] = job.vsamp[ci] = (nc == 3 && !ci) ? 2 : 1;
+    job.wblk[ci] = ((w + sub - 1) / sub + 7) / 8; job.hblk[ci] = ((h + sub - 1) / sub + 7) / 8;
+    job.has_quant[ci] = 1;
+    for (int i = 0; i < 64; ++i) job.quant[ci][i] = (uint16_t)(8 + (i & 7) * 3 + (i >> 3) * 3);
+    coef[ci].resize((size_t)job.wblk[ci] * job.hblk[ci] * 64);
+    fill(coef[ci], 17u + ci);
+    job.coef[ci] = coef[ci].data();
+  }
+  for (int rep = 0; rep < 4; ++rep) {
+    qs_hip_job j = job;
+    for (int ci = 0; ci < nc; ++ci) fill(coef[ci], 17u + ci);
+    char name[64];
+    snprintf(name, sizeof name, "qs_hip_do_quantsmooth q3 n3, call %d", rep + 1);
+    int r = 0;
+    PHASE(name, r = qs_hip_do_quantsmooth(&j, 0, 3, 0, nullptr, nullptr));
+    if (r) { printf("  -> %d %s\n", r, qs_hip_last_error()); return 1; }
+  }
+  printf("  %-46s %9.2f ms\n", "main() so far", now_ms() - t_main);
+  return 0;
+}
