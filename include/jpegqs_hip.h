@@ -90,7 +90,7 @@ int qs_hip_do_quantsmooth_rows(qs_hip_job *job, int16_t *const *const *rows, int
  * threads (their error text is not kept: results[i] carries the code).  results[i] =
  * what qs_hip_do_quantsmooth would have returned for jobs[i].  Returns 0, or < 0 when
  * the batch as a whole could not run (bad arguments, no device).  With several devices
- * configured (qs_hip_set_devices / QS_HIP_DEVICES / all visible) the jobs of a batch are spread
+ * configured (qs_hip_set_devices / QS_HIP_DEVICES) the jobs of a batch are spread
  * over them as whole jobs, balanced by block count: independent objects, no exchange.  Not part
  * of the reference API: an addition for callers that serve many images. */
 int qs_hip_do_quantsmooth_batch(qs_hip_job *const *jobs, int njobs, int flags, int niter, int *results);
@@ -102,9 +102,10 @@ int qs_hip_do_quantsmooth_batch(qs_hip_job *const *jobs, int njobs, int flags, i
  * pixel row per component from each neighbouring band after every pass A (hipMemcpyPeerAsync over
  * xGMI).  Bit-exact with the one-device result.  Both the independent-component flags (CLI
  * --quality 3/4) and the coupled YCbCr flags (--quality 5/6) are covered; anything else runs on
- * the current device.  The device list: qs_hip_set_devices(), else the environment variable
- * QS_HIP_DEVICES ("all", or ordinals such as "0,1,2,3"), else every visible device; fewer than
- * two entries = no sharding.  An ordinal may repeat (several bands on one GPU: how the route is
+ * the current device.  OPT-IN: by default everything runs on the caller's current HIP device (a process
+ * or thread per GPU is the usual deployment and must not find its jobs on other workers' GPUs).  The device
+ * list is given by qs_hip_set_devices(), else by the environment variable QS_HIP_DEVICES ("all", or ordinals
+ * such as "0,1,2,3"; read once per process); fewer than two entries = no sharding.  An ordinal may repeat (several bands on one GPU: how the route is
  * tested on a one-GPU box).  n = 0 returns to the default. */
 int qs_hip_set_devices(const int *devices, int n);
 /* the same job, cut over exactly these devices whatever its size (QS_HIP_ENOTSUP when the

@@ -34,23 +34,7 @@ EXTERN(void) jinit_d_main_controller JPP((j_decompress_ptr, boolean));
 EXTERN(void) jinit_inverse_dct JPP((j_decompress_ptr));
 EXTERN(void) jinit_upsampler JPP((j_decompress_ptr));
 EXTERN(void) jinit_color_deconverter JPP((j_decompress_ptr));
-#ifdef LIBJPEG_TURBO_VERSION
-/* leading part of libjpeg-turbo's private struct jpeg_decomp_master (jpegint.h), as far as the
- * field patched below; layout per version as in reference quantsmooth.h:44-60.  Compiled only
- * when the shim is built against libjpeg-turbo headers; this image has libjpeg 9d headers only,
- * so the branch is untested here (stated in DESIGN.md). */
-struct qs_turbo_master {
-	void (*prepare_for_output_pass) (j_decompress_ptr);
-	void (*finish_output_pass) (j_decompress_ptr);
-	boolean is_dummy_pass;
-#if LIBJPEG_TURBO_VERSION_NUMBER >= 2001090
-	boolean lossless;
-#endif
-	JDIMENSION first_iMCU_col, last_iMCU_col;
-	JDIMENSION first_MCU_col[MAX_COMPONENTS];
-	JDIMENSION last_MCU_col[MAX_COMPONENTS];
-};
-#endif
+#include "qs_turbo_master.h"   /* libjpeg-turbo only: the private master record patched after UPSAMPLE_UV */
 #endif
 
 /* Why the last do_quantsmooth() of this thread returned non-zero.  The reference's return value
@@ -67,9 +51,12 @@ int jpegqs_hip_backend_status(void) { return qs_backend_status; }
  * their copy into new virtual arrays.  Should a libjpeg error exit (longjmp) fall into that
  * window, the pointers stay parked here and the next call on this thread releases them. */
 static __thread void *qs_parked[2] = { NULL, NULL };
+/* ... and the component copies of the backing-store path (malloc'ed here) */
+static __thread int16_t *qs_copy[QS_HIP_MAXC] = { NULL, NULL, NULL, NULL };
 static void release_parked(void) {
 	int j;
 	for (j = 0; j < 2; j++) if (qs_parked[j]) { qs_hip_free(qs_parked[j]); qs_parked[j] = NULL; }
+	for (j = 0; j < QS_HIP_MAXC; j++) if (qs_copy[j]) { free(qs_copy[j]); qs_copy[j] = NULL; }
 }
 
 static double now_ms(void) {
@@ -165,7 +152,7 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 				(size_t)comp->height_in_blocks * sizeof(int16_t*));
 		for (blk_y = 0; blk_y < comp->height_in_blocks; blk_y++) {
 			JBLOCKARRAY buf = (*srcinfo->mem->access_virt_barray)
-					((j_common_ptr)srcinfo, coef_arrays[ci], blk_y, 1, TRUE);
+					((j_common_ptr)srcinfo, coef_arrays[ci], blk_y, 1, FALSE);   /* (read access: a swapped array is not marked dirty) */
 			rows[ci][blk_y] = (int16_t*)buf[0];
 		}
 		if (!rows_are_resident(srcinfo, rows[ci], comp->height_in_blocks,
@@ -176,8 +163,16 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 			size_t rowbytes;
 			comp = srcinfo->comp_info + ci;
 			rowbytes = (size_t)comp->width_in_blocks * sizeof(JBLOCK);
-			job.coef[ci] = (int16_t*)(*srcinfo->mem->alloc_large)((j_common_ptr)srcinfo, JPOOL_IMAGE,
-					rowbytes * comp->height_in_blocks);
+			/* plain malloc, not libjpeg's pool: one alloc_large request is limited to MAX_ALLOC_CHUNK
+			 * (about 1e9 bytes) and would stay allocated until the jpeg object is destroyed; the copy is
+			 * parked per thread so that a libjpeg error exit (longjmp) cannot leak it */
+			job.coef[ci] = qs_copy[ci] = (int16_t*)malloc(rowbytes * comp->height_in_blocks);
+			if (!job.coef[ci]) {
+				logfmt("jpegqs-hip: out of host memory\n");
+				qs_backend_status = QS_HIP_ENOMEM;
+				release_parked();
+				return 1;
+			}
 			for (blk_y = 0; blk_y < comp->height_in_blocks; blk_y++) {
 				JBLOCKARRAY buf = (*srcinfo->mem->access_virt_barray)
 						((j_common_ptr)srcinfo, coef_arrays[ci], blk_y, 1, FALSE);
@@ -208,6 +203,7 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 		/* no CPU fallback by design: report and leave the image untouched */
 		logfmt("jpegqs-hip: %s\n", qs_hip_last_error());
 		qs_backend_status = ret;
+		release_parked();
 		return 1;
 	}
 
@@ -220,7 +216,7 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 			if (job.has_quant[ci])
 				for (i = 0; i < DCTSIZE2; i++)
 					if (job.quant[ci][i] != srcinfo->comp_info[ci].quant_table->quantval[i]) { changed = 1; break; }
-		if (!changed) return ret;
+		if (!changed) { release_parked(); return ret; }
 	}
 
 	/* ---- copy path only: scatter the processed blocks back (in place there is nothing to do) */
@@ -234,6 +230,7 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 						((j_common_ptr)srcinfo, coef_arrays[ci], blk_y, 1, TRUE);
 				memcpy(buf[0], (char*)job.coef[ci] + rowbytes * blk_y, rowbytes);
 			}
+			free(qs_copy[ci]); qs_copy[ci] = NULL;
 		}
 
 	/* ---- UPSAMPLE_UV replaced the chroma arrays: new virtual arrays at luma
@@ -316,6 +313,12 @@ boolean jpegqs_start_decompress(j_decompress_ptr cinfo, jpegqs_control_t *opts) 
 			jpeg_finish_output(cinfo);
 		}
 		do_quantsmooth(cinfo, jpeg_read_coefficients(cinfo), opts);
+		/* The reference ignores the return value here (cancelled / rejected: the image decodes as it
+		 * is).  A GPU back end can also FAIL; the image then decodes unsmoothed, and that must not
+		 * pass silently: it is counted as a libjpeg warning (cinfo->err->num_warnings, what
+		 * applications check after decoding a damaged file) and jpegqs_hip_backend_status() keeps
+		 * the code for callers that know about it. */
+		if (jpegqs_hip_backend_status() < 0) cinfo->err->num_warnings++;
 		jpeg_start_output(cinfo, cinfo->input_scan_number);
 	}
 	return ret;

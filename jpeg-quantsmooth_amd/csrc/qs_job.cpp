@@ -262,25 +262,41 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
       if (comp[ci].processed && !comp[ci].dequant_only && *static_cast<const int32_t*>(comp[ci].hstatus.p))
         return JOB_RERUN_CAREFUL;                          // host input is still untouched
 
-  // ---- scatter the results (the only place host memory is written)
-  for (int ci = 0; ci < job->ncomp; ++ci) {
-    Comp& C = comp[ci];
-    if (!C.processed) continue;
-    std::vector<Piece> dst;
-    host_pieces(job, ci, 0, job->hblk[ci], 0, dst);
-    HIP_TRY(C.down.finish(C.coef.p, dst, C.stream));
-    if (C.have_up && !stop) {
-      if (C.down_up.staged) {
-        // the replacement array IS the pinned download buffer: it changes owner (qs_hip_free gives it
-        // back to the pool) instead of being copied into fresh, page-faulting malloc memory
-        HIP_TRY(C.down_up.finish(C.up.p, std::vector<Piece>{}, C.stream));     // (waits for its chunks)
-        up_host[ci - 1] = static_cast<int16_t*>(pinned_handout(C.down_up.stage));
-      } else {
-        up_host[ci - 1] = static_cast<int16_t*>(malloc(ubytes));
-        if (!up_host[ci - 1]) return qs_fail(QS_HIP_ENOMEM, "out of host memory");
-        HIP_TRY(C.down_up.finish(C.up.p, std::vector<Piece>{{up_host[ci - 1], 0, ubytes}}, C.stream));
+  // ---- scatter the results (the only place host memory is written).  Should a transfer fail after
+  // earlier components have been written, their original blocks are put back from the pinned upload
+  // staging: a reported failure leaves the image untouched.
+  auto scatter = [&]() -> int {
+    for (int ci = 0; ci < job->ncomp; ++ci) {
+      Comp& C = comp[ci];
+      if (!C.processed) continue;
+      std::vector<Piece> dst;
+      host_pieces(job, ci, 0, job->hblk[ci], 0, dst);
+      HIP_TRY(C.down.finish(C.coef.p, dst, C.stream));
+      if (C.have_up && !stop) {
+        if (C.down_up.staged) {
+          // the replacement array IS the pinned download buffer: it changes owner (qs_hip_free gives it
+          // back to the pool) instead of being copied into fresh, page-faulting malloc memory
+          HIP_TRY(C.down_up.finish(C.up.p, std::vector<Piece>{}, C.stream));     // (waits for its chunks)
+          up_host[ci - 1] = static_cast<int16_t*>(pinned_handout(C.down_up.stage));
+        } else {
+          up_host[ci - 1] = static_cast<int16_t*>(malloc(ubytes));
+          if (!up_host[ci - 1]) return qs_fail(QS_HIP_ENOMEM, "out of host memory");
+          HIP_TRY(C.down_up.finish(C.up.p, std::vector<Piece>{{up_host[ci - 1], 0, ubytes}}, C.stream));
+        }
       }
     }
+    return QS_HIP_OK;
+  };
+  if (int r = scatter()) {
+    for (int i = 0; i < nstreams; ++i) (void)hipStreamSynchronize(st.s[i]);
+    for (int ci = 0; ci < job->ncomp; ++ci) {
+      Comp& C = comp[ci];
+      if (!C.processed || !C.stage.p) continue;
+      std::vector<Piece> pcs;
+      host_pieces(job, ci, 0, job->hblk[ci], 0, pcs);
+      for (const Piece& pc : pcs) memcpy(pc.host, static_cast<const char*>(C.stage.p) + pc.off, pc.len);
+    }
+    return r;
   }
   if (trace_on())
     fprintf(stderr, "qs_hip trace: %s  enqueue %.2f ms (host->pinned->device issue %.2f)  drain %.2f ms  scatter %.2f ms\n",
@@ -321,10 +337,18 @@ bool qsj::job_needs_lowres(const qs_hip_job* job, int flags) {
          job->hsamp[1] == 1 && job->vsamp[1] == 1 && job->hsamp[2] == 1 && job->vsamp[2] == 1;
 }
 
+// Tuning knobs from the environment.  Read ONCE per name in a production process (getenv on every call
+// would race with a host application's setenv); with QS_HIP_TEST_HOOKS=1 they are re-read on every call,
+// which is how the tests lower thresholds inside one process.
 size_t qsj::env_size(const char* name, size_t dflt) {
-  const char* v = getenv(name);
-  const long long n = v ? atoll(v) : 0;
-  return n > 0 ? (size_t)n : dflt;
+  auto read = [&]() { const char* v = getenv(name); const long long n = v ? atoll(v) : 0; return n > 0 ? (size_t)n : dflt; };
+  if (test_hooks_on()) return read();
+  static std::mutex mu;
+  static std::vector<std::pair<std::string, size_t>> seen;
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& e : seen) if (e.first == name) return e.second;
+  seen.emplace_back(name, read());
+  return seen.back().second;
 }
 bool qsj::job_fusable(const qs_hip_job* job, int flags) {
   static const bool off = getenv("QS_HIP_NO_FUSE") != nullptr;
@@ -385,6 +409,7 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
   int maxj = 0;
   for (int ji : which) maxj = std::max(maxj, ji);
   std::vector<char> split(maxj + 1, 0), bad_job(maxj + 1, 0), scattered(maxj + 1, 0), defer(maxj + 1, 0);
+  std::vector<int> ngroups(maxj + 1, 0), ndone(maxj + 1, 0);   // groups a job's planes live in / groups whose results are back
   for (int ji : which) {
     const qs_hip_job* job = jobs[ji];
     size_t jblocks = 0;
@@ -424,6 +449,7 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
                           0, 0, job->hblk[ci]});
   }
   groups.remove_if([](const FGroup& g) { return g.planes.empty(); });   // placeholders left by band jobs
+  for (const FGroup& G : groups) for (int ji : G.jobs) ++ngroups[ji];
 
   // ---- per group: upload, niter x (pass A, pass B), status readback, download into pinned memory
   const int diag = (flags & QS_DIAGONALS) != 0;
@@ -509,6 +535,7 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
     for (const FPlane& P : G.planes)
       if (!bad_job[P.job]) { result_pieces(P, back); scattered[P.job] = 1; }
     HIP_TRY(G.down.finish(G.coef.p, back, G.s));
+    for (int ji : G.jobs) ++ndone[ji];
     // the group's stream work is complete: recycle its device arenas and download staging now, so
     // that memory in flight is bounded by the window below and not by the size of the batch.  The
     // upload staging of a band job stays (it is the restore copy): that is one image's worth.
@@ -519,7 +546,7 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
   // At most kWindow groups are in flight (about 200k blocks each: ~40 MiB of device memory and
   // ~50 MiB of pinned staging per group).
   static const size_t kWindow = env_size("QS_HIP_GROUP_WINDOW", 6);
-  {
+  auto pump = [&]() -> int {
     std::deque<FGroup*> inflight;
     for (FGroup& G : groups) {
       if (inflight.size() >= kWindow) {
@@ -532,24 +559,48 @@ static int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int
     t_enq = wall_ms();
     for (FGroup* G : inflight)
       if (int r = drain_group(*G)) return r;
-  }
-  for (FGroup* G : held) {
-    std::vector<Piece> back;
-    for (const FPlane& P : G->planes) if (!bad_job[P.job]) result_pieces(P, back);
-    HIP_TRY(G->down.finish(G->coef.p, back, G->s));
-  }
-  std::vector<int> rerun;
-  for (int ji : which) {
-    if (!bad_job[ji]) { results[ji] = 0; continue; }
-    rerun.push_back(ji);
-    if (!scattered[ji]) continue;                            // host input is still untouched
-    for (FGroup& G : groups)                                 // put the original rows back
+    for (FGroup* G : held) {
+      std::vector<Piece> back;
+      for (const FPlane& P : G->planes) if (!bad_job[P.job]) result_pieces(P, back);
+      HIP_TRY(G->down.finish(G->coef.p, back, G->s));
+      for (int ji : G->jobs) ++ndone[ji];
+    }
+    return QS_HIP_OK;
+  };
+  // the caller's rows of job ji <- the original input kept in the pinned upload staging
+  auto restore_job = [&](int ji) {
+    for (FGroup& G : groups)
       for (const FPlane& P : G.planes)
         if (P.job == ji && G.stage.p) {
           std::vector<Piece> pcs;
           result_pieces(P, pcs);
           for (const Piece& pc : pcs) memcpy(pc.host, static_cast<const char*>(G.stage.p) + pc.off, pc.len);
         }
+  };
+  if (int r = pump()) {
+    // Error exit (device out of memory, HIP failure) with groups in flight.  A banded job is scattered
+    // band by band, so some of its rows may already hold results while the call reports a failure:
+    // "image left untouched" must hold for callers that ignore the return value, as the reference's
+    // applications do.  Wait for everything queued, then either finish a job whose every group came
+    // back (its result is complete and checked) or put the original rows back.
+    for (auto& x : lease.p->s) (void)hipStreamSynchronize(x);
+    for (int ji : which) {
+      if (!scattered[ji]) continue;
+      if (!bad_job[ji] && ndone[ji] == ngroups[ji]) {
+        results[ji] = 0;
+        for (int ci = 0; ci < jobs[ji]->ncomp; ++ci)
+          for (int i = 0; i < 64; ++i) jobs[ji]->quant[ci][i] = 1;
+      } else {
+        restore_job(ji);
+      }
+    }
+    return r;
+  }
+  std::vector<int> rerun;
+  for (int ji : which) {
+    if (!bad_job[ji]) { results[ji] = 0; continue; }
+    rerun.push_back(ji);
+    if (scattered[ji]) restore_job(ji);                      // (otherwise the host input is still untouched)
   }
   if (trace_on())
     fprintf(stderr, "qs_hip trace: fused  %zu job(s) in %zu group(s)  enqueue %.2f ms  drain+download %.2f ms  (%zu re-run)\n",
@@ -805,7 +856,11 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
     for (int ci = 0; ci < 3; ++ci)
       host_pieces(jobs[which[g]], ci, 0, jobs[which[g]]->hblk[ci], cj[g].coef_off[ci], back);
   }
-  HIP_TRY(down.finish(coef.p, back, s));
+  if (hipError_t e = down.finish(coef.p, back, s)) {          // a late failure: put the original blocks back
+    (void)hipStreamSynchronize(s);
+    if (stage.p) for (const Piece& pc : back) memcpy(pc.host, static_cast<const char*>(stage.p) + pc.off, pc.len);
+    return qs_fail(QS_HIP_ENODEV, "download failed: %s", hipGetErrorString(e));
+  }
   // replacement arrays: first every transfer is completed (nothing handed out yet, so an error on the
   // way leaves no job half-updated), then ownership moves to the jobs
   struct UpArrays {
@@ -1019,6 +1074,7 @@ static int do_quantsmooth_batch_impl(qs_hip_job* const* jobs, int njobs, int fla
     } else {
       const size_t extra = tasks.size() >= 2 ? std::min<size_t>(3, tasks.size() - 1) : 0;   // more threads for the coupled jobs
       std::vector<std::thread> pool;
+      pool.reserve(nd + nd * extra);                          // no reallocation (bad_alloc) once threads are running
       size_t started = 1;                                     // devices [0, started) have their plane-set worker
       try {
         for (size_t d = 1; d < nd; ++d, ++started) pool.emplace_back(device_worker, d, true);

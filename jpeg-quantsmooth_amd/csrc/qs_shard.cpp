@@ -247,6 +247,23 @@ static int read_flags(Bands& bands, bool& bad) {
   return QS_HIP_OK;
 }
 
+// Error exit while the bands' results are being scattered: bands already written must not stay
+// behind in caller memory when the call reports a failure ("image left untouched").  Every band's
+// pinned upload staging still holds its original rows; put them back.  (A band whose upload went
+// straight from caller memory -- under 1 MiB, or pinned memory exhausted -- has no such copy.)
+static void restore_bands(Bands& bands, const qs_hip_job* job) {
+  for (Band& B : bands.b) {
+    (void)hipSetDevice(B.dev);
+    (void)hipStreamSynchronize(B.s);
+    if (!B.stage.p) continue;
+    std::vector<Piece> pcs;
+    for (const BandPlane& P : B.planes) host_pieces(job, P.ci, P.r0, P.hb, P.coef_off, pcs);
+    for (const Piece& pc : pcs) memcpy(pc.host, static_cast<const char*>(B.stage.p) + pc.off, pc.len);
+  }
+}
+#define HIP_TRY_RESTORE(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { restore_bands(bands, job); \
+  return qs_fail(e_ == hipErrorOutOfMemory ? QS_HIP_ENOMEM : QS_HIP_ENODEV, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+
 // ---------------------------------------------------------------------------
 // independent components: one plane set per band
 static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vector<int>& devices) {
@@ -311,11 +328,11 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
   if (int r = read_flags(bands, bad)) return r;
   if (bad) return JOB_RERUN_CAREFUL;                          // host input is still untouched
   for (Band& B : bands.b) {
-    HIP_TRY(hipSetDevice(B.dev));
+    HIP_TRY_RESTORE(hipSetDevice(B.dev));
     std::vector<Piece> back;
     for (const BandPlane& P : B.planes)
       host_pieces(job, P.ci, P.r0, P.hb, P.coef_off, back);
-    HIP_TRY(B.down.finish(B.coef.p, back, B.s));
+    HIP_TRY_RESTORE(B.down.finish(B.coef.p, back, B.s));
   }
   if (trace_on())
     fprintf(stderr, "qs_hip trace: sharded(set) %d band(s)  upload+stage %.2f ms  enqueue %.2f ms  drain+scatter %.2f ms\n",
@@ -494,15 +511,15 @@ static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::
     }
   struct UpFree { int16_t** p; bool keep; ~UpFree() { if (!keep) { free(p[0]); free(p[1]); } } } up_free{up_host, false};
   for (Band& B : bands.b) {
-    HIP_TRY(hipSetDevice(B.dev));
+    HIP_TRY_RESTORE(hipSetDevice(B.dev));
     std::vector<Piece> back;
     for (const BandPlane& P : B.planes)
       host_pieces(job, P.ci, P.r0, P.hb, P.coef_off, back);
-    HIP_TRY(B.down.finish(B.coef.p, back, B.s));
+    HIP_TRY_RESTORE(B.down.finish(B.coef.p, back, B.s));
     if (upsample)
       for (int j = 0; j < 2; ++j) {
         const BandPlane& Y = B.planes[0];
-        HIP_TRY(B.down_up[j].finish(B.aux[3 + j].p,
+        HIP_TRY_RESTORE(B.down_up[j].finish(B.aux[3 + j].p,
                                     std::vector<Piece>{{up_host[j] + (size_t)Y.r0 * Y.wb * 64, 0, (size_t)Y.hb * up_row}}, B.s));
       }
   }
@@ -561,9 +578,14 @@ static bool colour_shardable(const qs_hip_job* job, int flags, int niter) {
 std::vector<int> qsj::configured_devices() {
   std::vector<int> devs;
   std::lock_guard<std::mutex> lk(g_cfg_mu);
-  if (g_cfg_set) devs = g_cfg_devices;
-  else if (const char* v = getenv("QS_HIP_DEVICES")) devs = parse_devices(v);
-  else { const int n = qs_hip_device_count(); for (int i = 0; i < n; ++i) devs.push_back(i); }
+  if (g_cfg_set) return g_cfg_devices;
+  // QS_HIP_DEVICES is read once per process (getenv per call would race with a host application's setenv)
+  static const std::vector<int> from_env = [] { const char* v = getenv("QS_HIP_DEVICES"); return v ? parse_devices(v) : std::vector<int>(); }();
+  if (!from_env.empty()) return from_env;
+  // Default: the caller's current device only.  A process (or thread) per GPU is the common deployment;
+  // spreading over every visible GPU is something the caller opts into (qs_hip_set_devices, or
+  // QS_HIP_DEVICES=all / a list).
+  devs.push_back(current_device());
   return devs;
 }
 

@@ -47,11 +47,17 @@ inline size_t round_size(size_t n) {               // size classes: powers of tw
   return c;
 }
 
-// Test hook (tests/test_gpu_faults.py): QS_HIP_TEST_FAIL_ALLOC=N makes the N-th device allocation
-// request after the variable was set or changed fail once with hipErrorOutOfMemory, so that the error
-// paths of the job layer (drain guards, pool returns, fall-backs, compute slots) can be exercised.
-// QS_HIP_TEST_FAIL_PINNED=N does the same for pinned host buffers (the transfers then take their
-// pageable fall-backs, or the call reports QS_HIP_ENOMEM where a pinned block is indispensable).
+// Test hooks (tests/test_gpu_faults.py), live only when the process was started with QS_HIP_TEST_HOOKS=1 (read
+// once: a production process never calls getenv on these paths, which would race with a host application
+// that calls setenv from another thread).  QS_HIP_TEST_FAIL_ALLOC=N makes the N-th device allocation request
+// after the variable was set or changed fail once with hipErrorOutOfMemory, so that the error paths of the
+// job layer (drain guards, pool returns, fall-backs, compute slots) can be exercised.
+// QS_HIP_TEST_FAIL_PINNED=N does the same for pinned host buffers (the transfers then take their pageable
+// fall-backs, or the call reports QS_HIP_ENOMEM where a pinned block is indispensable);
+// QS_HIP_TEST_FAIL_FINISH=N makes the N-th Download::finish report a HIP error AFTER it has written its
+// pieces to caller memory (a late failure while results are being scattered: the caller's arrays must be
+// restored).
+inline bool test_hooks_on() { static const bool on = getenv("QS_HIP_TEST_HOOKS") != nullptr; return on; }
 struct TestFault {
   const char* name;
   std::atomic<bool> armed{false};
@@ -60,8 +66,9 @@ struct TestFault {
   long countdown = 0;
   explicit TestFault(const char* n) : name(n) {}
   bool fire() {
+    if (!test_hooks_on()) return false;
     const char* v = getenv(name);
-    if (!v) {                                         // (the production path: one getenv per buffer request)
+    if (!v) {
       if (armed.load(std::memory_order_relaxed)) { std::lock_guard<std::mutex> lk(mu); seen.clear(); armed = false; }
       return false;
     }
@@ -72,6 +79,7 @@ struct TestFault {
 };
 inline bool test_fail_alloc() { static TestFault f("QS_HIP_TEST_FAIL_ALLOC"); return f.fire(); }
 inline bool test_fail_pinned() { static TestFault f("QS_HIP_TEST_FAIL_PINNED"); return f.fire(); }
+inline bool test_fail_finish() { static TestFault f("QS_HIP_TEST_FAIL_FINISH"); return f.fire(); }
 
 struct DevBuf {
   void* p = nullptr;
@@ -133,6 +141,7 @@ struct PinnedBuf {
   ~PinnedBuf() { release(); }
   static std::vector<CacheEntry>& pool() { static std::vector<CacheEntry> v; return v; }   // (inline function: one per library)
   bool alloc(size_t bytes) {
+    release();                                     // (a reused object must not leak the block it holds)
     if (test_fail_pinned()) return false;
     const size_t want = round_size(bytes);
     {
@@ -340,9 +349,13 @@ struct Download {
                                     hipMemcpyDeviceToHost, s);
       hipEvent_t evt = nullptr;
       if (e == hipSuccess) e = hipEventCreateWithFlags(&evt, hipEventDisableTiming);
-      if (e != hipSuccess) return e;
-      ev.push_back(evt);
-      if ((e = hipEventRecord(evt, s)) != hipSuccess) return e;
+      if (e == hipSuccess) { ev.push_back(evt); e = hipEventRecord(evt, s); }
+      if (e != hipSuccess) {                       // nothing usable was staged: wait_first / finish must not index ev[]
+        (void)hipStreamSynchronize(s);             // (a chunk copy may be in flight into `stage`)
+        reset();
+        bytes = nbytes;
+        return e;
+      }
     }
     return hipSuccess;
   }
@@ -355,7 +368,9 @@ struct Download {
         hipError_t e = hipMemcpyAsync(pc.host, static_cast<const char*>(src) + pc.off, pc.len, hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) return e;
       }
-      return hipStreamSynchronize(s);
+      hipError_t e = hipStreamSynchronize(s);
+      if (e == hipSuccess && test_fail_finish()) e = hipErrorUnknown;
+      return e;
     }
     // a chunk is handed to the helpers only once it has arrived: a helper never waits
     // for the GPU, so transfers of other host threads are not held up behind this one
@@ -371,6 +386,7 @@ struct Download {
         hs.push_back(HostPool::get().submit(kStageThreads, [=](int t) { copy_item(stg, *pcs, nbytes, c * kStageThreads + t, false); }));
     }
     for (auto& h : hs) HostPool::wait(h);
+    if (e == hipSuccess && test_fail_finish()) e = hipErrorUnknown;
     return e;
   }
 };

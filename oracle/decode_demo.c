@@ -45,6 +45,14 @@ int main(int argc, char **argv) {
 	jpeg_read_header(&ci, TRUE);
 	ci.dct_method = JDCT_ISLOW;
 	jpegqs_start_decompress(&ci, &opts);
+#ifndef USE_REFERENCE
+	if (jpegqs_hip_backend_status() < 0 || err.num_warnings) {   /* the GPU back end failed: say so, deliver nothing */
+		fprintf(stderr, "decode_demo: back end failed (status %d, %ld libjpeg warning(s))\n",
+				jpegqs_hip_backend_status(), err.num_warnings);
+		jpeg_destroy_decompress(&ci);
+		return 3;
+	}
+#endif
 	row = (JSAMPROW)malloc((size_t)ci.output_width * ci.output_components);
 	fprintf(stderr, "%ux%ux%d\n", ci.output_width, ci.output_height, ci.output_components);
 	while (ci.output_scanline < ci.output_height) {

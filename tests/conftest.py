@@ -8,6 +8,10 @@ ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
+# test hooks of the product library (fault injection, per-call re-reading of the tuning environment
+# variables): must be in the environment before the library initialises, see csrc/qs_xfer.h
+os.environ.setdefault("QS_HIP_TEST_HOOKS", "1")
+
 import jpegqs_pkg  # noqa: E402
 
 GOLDEN = Path(__file__).resolve().parent / "golden"

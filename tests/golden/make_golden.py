@@ -124,5 +124,32 @@ def make_cli_golden():
     print(sorted(p.name for p in out.iterdir()))
 
 
+DECODE_CASES = [("gray64", 4, 2), ("rgb141x93_420", 3, 3), ("rgb128x96_420", 3, 2), ("rgb128x96_420", 5, 2),
+                ("rgb141x93_444", 6, 3), ("gray64", 6, 2), ("rgb141x93_444", 5, 2)]
+DECODE_ABORT_CASES = [("rgb141x93_420", 6, 3), ("rgb128x96_420", 6, 1)]
+
+
+def make_decode_golden():
+    """decode-mode API (jpegqs_start_decompress ... jpeg_read_scanlines): raw pixels delivered by the
+    reference compiled into oracle/decode_demo.c (oracle/_ref/decode_ref_none).  For UPSAMPLE_UV on a
+    subsampled image the reference's own decode mode dies inside libjpeg 9d's jinit_upsampler
+    ("Fractional sampling not implemented yet"): that text and exit status are recorded too, the
+    product has to behave the same way."""
+    import subprocess
+    out = OUT / "cli"
+    demo = ROOT / "oracle" / "_ref" / "decode_ref_none"
+    for src, q, n in DECODE_CASES:
+        r = subprocess.run([str(demo), str(q), str(n), str(out / f"{src}.jpg")], capture_output=True, check=True)
+        dst = out / f"{src}.q{q}.dec.ref.raw"
+        if dst.exists():
+            assert dst.read_bytes() == r.stdout, f"{dst.name} changed"
+        dst.write_bytes(r.stdout)
+    for src, q, n in DECODE_ABORT_CASES:
+        r = subprocess.run([str(demo), str(q), str(n), str(out / f"{src}.jpg")], capture_output=True)
+        assert r.returncode != 0
+        (out / f"{src}.q{q}.dec.abort.txt").write_text(f"{r.returncode}\n{r.stderr.decode()}")
+
+
 if __name__ == "__main__":
     make_cli_golden()
+    make_decode_golden()

@@ -98,3 +98,43 @@ def test_bad_arguments_rejected(pkg, hip):
 def test_missing_library_fails_loudly(pkg, tmp_path):
     with pytest.raises(FileNotFoundError):
         pkg.load_library(tmp_path / "libjpegqs_hip.so")
+
+
+CSRC = ROOT / "jpeg-quantsmooth_amd" / "csrc"
+JPEGINC = "/opt/conda/include"
+
+
+@pytest.mark.parametrize("turbo_number", [3000090, 2001000, 2000090])
+def test_turbo_branch_of_the_shim_compiles_and_matches_reference_layout(turbo_number):
+    """decode mode after UPSAMPLE_UV patches libjpeg-turbo's PRIVATE master record (reference
+    quantsmooth.h:44-60, 2864-2867).  This image has libjpeg 9d headers only, so the branch cannot run
+    here; it is at least compiled -- against tests/stubs/turbo/jpeglib.h, which dresses the 9d header up as
+    libjpeg-turbo of the given version -- with _Static_asserts on the record's layout, and, where the
+    reference is mounted, every field offset is compared with the reference's own declaration."""
+    import subprocess
+    if not Path(JPEGINC, "jpeglib.h").exists():
+        pytest.skip("no libjpeg headers")
+    base = ["gcc", "-fsyntax-only", "-Werror=implicit-function-declaration", f"-I{ROOT / 'tests' / 'stubs' / 'turbo'}",
+            f"-I{JPEGINC}", f"-DQS_STUB_TURBO_NUMBER={turbo_number}"]
+    r = subprocess.run(base + [str(CSRC / "jpegqs_shim.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    if Path("/root/reference/quantsmooth.h").exists():
+        r = subprocess.run(base + ["-I/root/reference", f"-I{CSRC}", "-DNO_SIMD", "-w",
+                                   str(ROOT / "tests" / "stubs" / "turbo_layout_check.c")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
+def test_decode_mode_reports_a_backend_failure(hip):
+    """jpegqs_start_decompress() with no usable GPU: the reference API has no error return there (reference
+    quantsmooth.h:2880-2895 ignores do_quantsmooth's result), so the failure is counted as a libjpeg warning
+    and kept in jpegqs_hip_backend_status(); the demo program exits 3 instead of delivering unsmoothed pixels"""
+    import os
+    import subprocess
+    demo = ROOT / "oracle" / "decode_hip"
+    if not demo.exists():
+        pytest.fail(f"{demo} not built (run __graft_entry__.build())")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")     # hide every device
+    r = subprocess.run([str(demo), "3", "2", str(ROOT / "tests" / "golden" / "cli" / "gray64.jpg")], capture_output=True, env=env)
+    assert r.returncode == 3, (r.returncode, r.stderr.decode())
+    assert b"no HIP device" in r.stderr and b"back end failed (status -1" in r.stderr
+    assert r.stdout == b""

@@ -148,18 +148,33 @@ DECODE = ROOT / "oracle" / "decode_hip"   # oracle/decode_demo.c linked against 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("src,quality,niter", [("gray64", 4, 2), ("rgb141x93_420", 3, 3),
-                                               ("rgb128x96_420", 3, 2), ("rgb128x96_420", 5, 2)])
+                                               ("rgb128x96_420", 3, 2), ("rgb128x96_420", 5, 2),
+                                               ("rgb141x93_444", 6, 3), ("gray64", 6, 2), ("rgb141x93_444", 5, 2)])
 def test_decode_mode_matches_reference_pixels(gpu, src, quality, niter):
     """jpeg_read_scanlines() after jpegqs_start_decompress() delivers the same
     pixels as the reference built into the same demo program (reference
-    quantsmooth.h:2861-2905).  UPSAMPLE_UV (q=6) is not covered: the reference's
-    own decode mode aborts with "Fractional sampling not implemented yet" under
-    the libjpeg 9d of this image, so there is nothing to compare against."""
+    quantsmooth.h:2861-2905).  --quality 6 on images WITHOUT chroma subsampling
+    (4:4:4, gray) takes the JOINT_YUV path and no upsampling: pixels must be equal.
+    UPSAMPLE_UV on a subsampled image: see the next test."""
     if not DECODE.exists():
         pytest.fail(f"{DECODE} not built (run __graft_entry__.build())")
     r = subprocess.run([str(DECODE), str(quality), str(niter), str(GOLD / f"{src}.jpg")], capture_output=True)
     assert r.returncode == 0, r.stderr.decode()
     assert r.stdout == (GOLD / f"{src}.q{quality}.dec.ref.raw").read_bytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src,quality,niter", [("rgb141x93_420", 6, 3), ("rgb128x96_420", 6, 1)])
+def test_decode_mode_after_upsample_behaves_like_the_reference(gpu, src, quality, niter):
+    """UPSAMPLE_UV on a 4:2:0 image in decode mode: the reference itself, compiled against the libjpeg 9d of
+    this image, dies inside jinit_upsampler with libjpeg's "Fractional sampling not implemented yet" (the
+    re-initialisation of reference quantsmooth.h:2861-2876 targets libjpeg-turbo / libjpeg <= 8).  The product runs
+    the same libjpeg call sequence after its GPU pass, so it must end the same way: same message, same status."""
+    want_rc, want_err = (GOLD / f"{src}.q{quality}.dec.abort.txt").read_text().split("\n", 1)
+    r = subprocess.run([str(DECODE), str(quality), str(niter), str(GOLD / f"{src}.jpg")], capture_output=True)
+    got_err = "\n".join(l for l in r.stderr.decode().splitlines() if "amdgpu.ids" not in l)
+    assert r.returncode == int(want_rc)
+    assert got_err.strip() == want_err.strip()
 
 
 @pytest.mark.gpu

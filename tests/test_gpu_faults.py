@@ -144,3 +144,70 @@ def test_pinned_allocation_failure(gpu, oracle, synth, monkeypatch, nth, flags):
                 assert_same_result(a, _want(oracle, j, flags, 1), f"batch job {k} (nth={nth}, flags={flags})")
     again = gpu.do_quantsmooth(job["coefs"], job["quants"], flags, 1, **kw)
     assert_same_result(again, want, f"after an injected pinned failure (nth={nth}, flags={flags})")
+
+
+def _raw_call(gpu, job, flags, niter, devices=None):
+    """the C entry point on arrays we keep: -> (return code, the arrays the library worked on, the job struct)"""
+    import ctypes as C
+    from jpeg_quantsmooth_amd.hipqs import PROGRESS_FN
+    kw = {n: job[n] for n in ("hsamp", "vsamp", "colorspace", "image_size") if n in job}
+    j, work = gpu._make_job(job["coefs"], job["quants"], kw.get("hsamp"), kw.get("vsamp"), kw.get("colorspace"), kw.get("image_size"))
+    if devices:
+        arr = (C.c_int * len(devices))(*devices)
+        rc = gpu.lib.qs_hip_do_quantsmooth_sharded(C.byref(j), flags, niter, arr, len(devices))
+    else:
+        rc = gpu.lib.qs_hip_do_quantsmooth(C.byref(j), flags, niter, 0, C.cast(None, PROGRESS_FN), None)
+    return rc, work, j
+
+
+@pytest.mark.parametrize("route", ["general", "sharded-set", "sharded-colour"])
+@pytest.mark.parametrize("nth", [1, 2])
+def test_reported_failure_leaves_the_image_untouched(gpu, oracle, synth, monkeypatch, route, nth):
+    """results are scattered to caller memory piece by piece (per component, per band); a
+    failure AFTER some pieces have been written must put the original blocks back -- the reference's
+    applications ignore do_quantsmooth's return value and would write a half-smoothed, dequantised image
+    with unchanged quant tables.  QS_HIP_TEST_FAIL_FINISH=N: the N-th scatter reports a HIP error after
+    writing its pieces."""
+    big = synth.synth_ycc(1024, 768, 2, 2, quality=50, seed=11)          # > 1 MiB per component: staged transfers
+    job = dict(coefs=big["coefs"], quants=big["quants"], hsamp=big["hsamp"], vsamp=big["vsamp"], colorspace=3, image_size=(1024, 768))
+    flags, devices = {"general": (7, None), "sharded-set": (1, [0, 0, 0]), "sharded-colour": (7, [0, 0, 0])}[route]
+    monkeypatch.setenv("QS_HIP_TEST_FAIL_FINISH", f"{nth}")
+    try:
+        rc, work, j = _raw_call(gpu, job, flags, 2, devices)
+    finally:
+        monkeypatch.delenv("QS_HIP_TEST_FAIL_FINISH")
+    assert rc < 0, "the injected transfer failure must be reported"
+    for ci in range(3):
+        assert np.array_equal(work[ci], job["coefs"][ci]), f"{route}: component {ci} was left modified after a reported failure"
+        assert list(j.quant[ci][:]) == [int(v) for v in job["quants"][ci]], f"{route}: quant table {ci} changed"
+    assert j.up_wblk == 0
+    kw = {n: job[n] for n in ("hsamp", "vsamp", "colorspace", "image_size")}
+    again = gpu.do_quantsmooth(job["coefs"], job["quants"], flags, 2, devices=devices, **kw)
+    assert_same_result(again, _want(oracle, job, flags, 2), f"{route}: the call after the injected failure")
+
+
+def test_reported_failure_leaves_a_banded_image_untouched():
+    """the same for the fused route with the plane cut into pipelined bands (run_fused): bands are written back
+    while later bands are still in flight; the failing scatter is the 2nd / 3rd / last band's"""
+    from test_gpu_parity import _BAND_ENV, _run_py
+    code = r'''
+import sys, ctypes as C, os, numpy as np
+sys.path.insert(0, "tests")
+import jpegqs_pkg
+from oracle.oracle import Oracle
+from helpers import assert_same_result
+from jpeg_quantsmooth_amd.hipqs import PROGRESS_FN
+pkg = jpegqs_pkg.load(); hip = pkg.HipQS(); O = Oracle()
+coef, quant = pkg.synth.synth_gray(64, 512, 50, seed=3)          # 8 x 64 blocks -> 13 bands of <= 5 rows + halo
+for nth in (2, 3, 13):
+    j, work = hip._make_job([coef], [quant])
+    os.environ["QS_HIP_TEST_FAIL_FINISH"] = str(nth)
+    rc = hip.lib.qs_hip_do_quantsmooth(C.byref(j), 1, 2, 0, C.cast(None, PROGRESS_FN), None)
+    del os.environ["QS_HIP_TEST_FAIL_FINISH"]
+    assert rc < 0, (nth, rc)
+    assert np.array_equal(work[0], coef), f"nth={nth}: rows left modified after a reported failure"
+    assert list(j.quant[0][:]) == [int(v) for v in quant]
+    assert_same_result(hip.do_quantsmooth([coef], [quant], 1, 2), O.do_quantsmooth([coef], [quant], 1, 2), f"after nth={nth}")
+print("ok")
+'''
+    assert "ok" in _run_py(code, dict(_BAND_ENV, QS_HIP_TEST_HOOKS="1"))
