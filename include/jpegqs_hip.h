@@ -112,6 +112,19 @@ int qs_hip_set_devices(const int *devices, int n);
  * flag / table combination has no sharded route; a progress callback is not available here) */
 int qs_hip_do_quantsmooth_sharded(qs_hip_job *job, int flags, int niter, const int *devices, int ndev);
 
+/* The band arithmetic itself -- ONE definition, used by the in-process route above (csrc/qs_shard.cpp: halo rows
+ * pulled with hipMemcpyPeerAsync) and by the one-process-per-GPU driver (bands.py: the same rows sent with RCCL):
+ * block rows [*row0, *row1) of band `band` of `nbands` (edges on multiples of `align` block rows);
+ * the luma / chroma row ranges of a band of a coupled YCbCr job (cut on chroma block rows, luma = the v_samp
+ * times taller range of the same image rows; the last band takes the remaining luma rows);
+ * and the byte offsets, inside a band's pixel plane, of the two rows it sends (first / last pixel row) and of
+ * the two apron rows it receives into, each *nbytes long (reference quantsmooth.h:1396-1401 is what reads them). */
+int qs_hip_band_rows(int hblk, int nbands, int band, int align, int *row0, int *row1);
+int qs_hip_colour_band_rows(int hblk_luma, int hblk_chroma, int v_samp, int nbands, int band,
+		int *y0, int *y1, int *c0, int *c1);
+int qs_hip_band_halo_rows(int wblk, int hblk, size_t *send_top, size_t *send_bot,
+		size_t *recv_top, size_t *recv_bot, size_t *nbytes);
+
 void qs_hip_free(void *p);
 /* the job layer keeps freed device buffers (up to 6 GiB per device), pinned staging buffers (up
  * to 2 GiB) and HIP streams in process-wide caches, each entry tied to the device it was created

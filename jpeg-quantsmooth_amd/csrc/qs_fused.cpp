@@ -1,0 +1,277 @@
+// qs_fused.cpp -- the plane-set route of the job layer: jobs whose components are independent of each
+// other run as ONE pass-A and ONE pass-B launch per iteration over all their planes; a very large plane
+// is cut into pipelined bands.  (Split out of qs_job.cpp; semantics in qs_jobint.h.)
+#include <list>
+
+#include "qs_jobint.h"
+
+using namespace qsx;
+using namespace qsj;
+
+// ---------------------------------------------------------------------------
+// fused execution: jobs whose components are independent of each other (no
+// JOINT_YUV / UPSAMPLE_UV coupling, no LOW_QUALITY, ordinary quant tables) run
+// as plane sets -- ONE pass-A and ONE pass-B launch per iteration for all
+// components of all jobs of a group (qs_*_set_kernel), so that small images
+// fill the chip together and a job does not occupy three hardware queues.
+// Everything else about the job semantics is as in run_job (eager mode): the
+// range-check flags are read once at the end, a job with a set flag is re-run in
+// the careful order from its untouched host input.
+
+namespace {
+// One device plane of a set: a whole component, or a band of block rows of a very large
+// one (rows [src_row0, src_row0 + hb) of the source, of which [keep0, keep1) are results:
+// the rest is halo, see split_rows).
+struct FPlane { int job, ci, wb, hb, cst; size_t coef_off, px_off, cbytes; int src_row0, keep0, keep1; };
+struct FGroup {
+  std::vector<FPlane> planes;
+  std::vector<int> jobs;                  // indices into the caller's job list
+  DevBuf coef, px, cst, status;
+  PinnedBuf stage;
+  std::vector<QsConsts> hc;               // host copies stay alive until the stream is drained
+  PinnedBuf hstatus;                      // range-check flags
+  Download down;                          // results on their way back
+  hipStream_t s = nullptr;
+  size_t blocks = 0, coef_bytes = 0;
+  // everything queued on the group's stream has completed: give the arenas back
+  void release_transients(bool keep_stage) {
+    coef.release(); px.release(); cst.release(); status.release();
+    hstatus.release(); down.reset();
+    if (!keep_stage) stage.release();
+  }
+};
+
+// a group of >= 3 waves per SIMD runs at the streaming rate; smaller groups let the upload of one
+// overlap the kernels of the previous and the download of the one before (three streams)
+static const size_t kGroupBlocks = (size_t)200 << 10;
+// A plane above kSplitBlocks is cut into bands of about kBandBlocks that travel as separate
+// groups, so its upload, kernels and download overlap as they do for a batch of small jobs.
+// A block's result after n iterations depends only on blocks within n rows of it, so a band
+// carries n extra block rows on each cut side (recomputed, not copied back): bit-exact.
+// (QS_HIP_SPLIT_BLOCKS / QS_HIP_BAND_BLOCKS override the two sizes: the tests use them to run
+// the band logic on small images.)
+static const size_t kSplitBlocks = env_size("QS_HIP_SPLIT_BLOCKS", (size_t)512 << 10),
+                    kBandBlocks = env_size("QS_HIP_BAND_BLOCKS", (size_t)256 << 10);
+
+}  // namespace
+
+int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int flags, int niter, int* results) {
+  StreamLease lease;
+  if (!lease.p) return qs_fail(QS_HIP_ENODEV, "could not create HIP streams: %s", hipGetErrorString(hipGetLastError()));
+  std::list<FGroup> groups;
+  DrainGuard drain{lease.p};
+  const double t_start = wall_ms();
+  double t_enq = t_start;
+
+  // ---- partition into groups (a job never straddles two, unless it is cut into bands)
+  int maxj = 0;
+  for (int ji : which) maxj = std::max(maxj, ji);
+  std::vector<char> split(maxj + 1, 0), bad_job(maxj + 1, 0), scattered(maxj + 1, 0), defer(maxj + 1, 0);
+  std::vector<int> ngroups(maxj + 1, 0), ndone(maxj + 1, 0);   // groups a job's planes live in / groups whose results are back
+  for (int ji : which) {
+    const qs_hip_job* job = jobs[ji];
+    size_t jblocks = 0;
+    bool big = false;
+    for (int ci = 0; ci < job->ncomp; ++ci) {
+      const size_t nb = (size_t)job->wblk[ci] * job->hblk[ci];
+      jblocks += nb;
+      const int bands = (int)((nb + kBandBlocks - 1) / kBandBlocks);
+      if (nb > kSplitBlocks && (job->hblk[ci] + bands - 1) / bands >= 8 * niter) big = true;   // halo <= 25 %
+    }
+    if (big) {
+      split[ji] = 1;
+      for (int ci = 0; ci < job->ncomp; ++ci) {
+        const int wb = job->wblk[ci], hb = job->hblk[ci];
+        const int bands = std::max(1, (int)(((size_t)wb * hb + kBandBlocks - 1) / kBandBlocks));
+        const int rows = (hb + bands - 1) / bands;
+        for (int r0 = 0; r0 < hb; r0 += rows) {
+          const int r1 = std::min(hb, r0 + rows), d0 = std::max(0, r0 - niter), d1 = std::min(hb, r1 + niter);
+          groups.emplace_back();
+          FGroup& G = groups.back();
+          G.jobs.push_back(ji);
+          G.blocks = (size_t)wb * (d1 - d0);
+          G.planes.push_back({ji, ci, wb, d1 - d0, -1, 0, 0, (size_t)wb * (d1 - d0) * 128, d0, r0 - d0, r1 - d0});
+        }
+      }
+      groups.emplace_back();                                 // the next job starts a fresh group
+      continue;
+    }
+    if (groups.empty() || (int)groups.back().planes.size() + job->ncomp > QS_MAX_PLANES ||
+        (groups.back().blocks && groups.back().blocks + jblocks > kGroupBlocks))
+      groups.emplace_back();
+    FGroup& G = groups.back();
+    G.jobs.push_back(ji);
+    G.blocks += jblocks;
+    for (int ci = 0; ci < job->ncomp; ++ci)
+      G.planes.push_back({ji, ci, job->wblk[ci], job->hblk[ci], -1, 0, 0, (size_t)job->wblk[ci] * job->hblk[ci] * 128,
+                          0, 0, job->hblk[ci]});
+  }
+  groups.remove_if([](const FGroup& g) { return g.planes.empty(); });   // placeholders left by band jobs
+  for (const FGroup& G : groups) for (int ji : G.jobs) ++ngroups[ji];
+
+  // ---- per group: upload, niter x (pass A, pass B), status readback, download into pinned memory
+  const int diag = (flags & QS_DIAGONALS) != 0;
+  size_t gi = 0;
+  auto enqueue = [&](FGroup& G) -> int {
+    G.s = lease.p->s[gi++ % 3];
+    const int np = (int)G.planes.size();
+    size_t coef_bytes = 0, px_bytes = 0;
+    std::vector<const uint16_t*> qtabs;
+    for (FPlane& P : G.planes) {
+      P.coef_off = coef_bytes; coef_bytes += P.cbytes;
+      P.px_off = px_bytes; px_bytes += (qs_hip_plane_bytes(P.wb, P.hb) + 255) & ~(size_t)255;
+      const uint16_t* q = jobs[P.job]->quant[P.ci];
+      for (size_t k = 0; k < qtabs.size() && P.cst < 0; ++k)
+        if (!memcmp(qtabs[k], q, 64 * sizeof(uint16_t))) P.cst = (int)k;
+      if (P.cst < 0) { P.cst = (int)qtabs.size(); qtabs.push_back(q); }
+    }
+    HIP_TRY(G.coef.alloc(coef_bytes));
+    HIP_TRY(G.px.alloc(px_bytes));
+    HIP_TRY(G.cst.alloc(qtabs.size() * sizeof(QsConsts)));
+    HIP_TRY(G.status.alloc((size_t)np * sizeof(int32_t)));
+    G.hc.resize(qtabs.size());
+    for (size_t k = 0; k < qtabs.size(); ++k)
+      if (int r = qs_hip_consts_build(&G.hc[k], qtabs[k], flags)) return r;
+    HIP_TRY(hipMemcpyAsync(G.cst.p, G.hc.data(), qtabs.size() * sizeof(QsConsts), hipMemcpyHostToDevice, G.s));
+    std::vector<Piece> pieces;
+    for (const FPlane& P : G.planes)
+      host_pieces(jobs[P.job], P.ci, P.src_row0, P.hb, P.coef_off, pieces);
+    G.coef_bytes = coef_bytes;
+    HIP_TRY(upload_pieces(G.coef.p, pieces, coef_bytes, G.s, G.stage));
+    HIP_TRY(hipMemsetAsync(G.status.p, 0, (size_t)np * sizeof(int32_t), G.s));
+
+    QsPlaneSet set;
+    memset(&set, 0, sizeof set);
+    set.n = np;
+    int w = 0;
+    for (int i = 0; i < np; ++i) {
+      const FPlane& P = G.planes[i];
+      set.wave0[i] = w;
+      w += (P.wb * P.hb + 63) / 64;
+      QsPlaneRef& R = set.ref[i];
+      R.cst = G.cst.as<QsConsts>() + P.cst;
+      R.coef = reinterpret_cast<int16_t*>(G.coef.as<char>() + P.coef_off);
+      R.plane = G.px.as<uint8_t>() + P.px_off;
+      R.status = G.status.as<int32_t>() + i;
+      R.wblk = P.wb; R.hblk = P.hb; R.pitch = qs_plane_pitch(P.wb);
+      R.mode = QS_PLANE_REP_TOP | QS_PLANE_REP_BOT | (comp_rebalance(jobs[P.job], P.ci, flags) ? QS_PLANE_REBALANCE : 0);
+    }
+    for (int i = np; i < QS_MAX_PLANES + 2; ++i) set.wave0[i] = w;
+    for (int it = 0; it < niter; ++it) {
+      qs_launch_idct_set(set, it == 0, G.s);
+      qs_launch_smooth_set(set, diag, it == niter - 1, G.s);
+    }
+    HIP_TRY(hipGetLastError());
+    // pinned: a pageable destination would make this call wait for the whole stream
+    if (!G.hstatus.alloc((size_t)np * sizeof(int32_t))) return qs_fail(QS_HIP_ENOMEM, "out of pinned host memory");
+    HIP_TRY(hipMemcpyAsync(G.hstatus.p, G.status.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, G.s));
+    HIP_TRY(G.down.issue(G.coef.p, coef_bytes, G.s, rows_active()));       // to pinned memory, right behind the kernels
+    // a band job is scattered band by band; without the staging copy of its input (pinned memory
+    // exhausted) nothing could be restored should a later band trip the range check: hold it back
+    if (!G.stage.p) for (int ji : G.jobs) if (split[ji]) defer[ji] = 1;
+    return QS_HIP_OK;
+  };
+
+  // ---- drain a group; results go back only for jobs whose range check passed.
+  // A job cut into bands is scattered band by band before its later bands have been
+  // checked: should one of those trip the range check after all (crafted file), the rows
+  // already written are restored from the pinned upload staging, which still holds the
+  // original input.  Without that staging copy the job's bands are held back until all of
+  // them have been checked.
+  auto result_pieces = [&](const FPlane& P, std::vector<Piece>& out) {   // the rows of P that are results (not halo)
+    host_pieces(jobs[P.job], P.ci, P.src_row0 + P.keep0, P.keep1 - P.keep0, P.coef_off + (size_t)P.keep0 * P.wb * 128, out);
+  };
+  std::vector<FGroup*> held;
+  auto drain_group = [&](FGroup& G) -> int {
+    HIP_TRY(G.down.wait_first(G.s));
+    const int32_t* hst = static_cast<const int32_t*>(G.hstatus.p);
+    for (size_t i = 0; i < G.planes.size(); ++i) if (hst[i]) bad_job[G.planes[i].job] = 1;
+    bool hold = false, banded = false;
+    for (int ji : G.jobs) { hold |= (defer[ji] != 0); banded |= (split[ji] != 0); }
+    if (hold) { held.push_back(&G); return QS_HIP_OK; }
+    std::vector<Piece> back;
+    for (const FPlane& P : G.planes)
+      if (!bad_job[P.job]) { result_pieces(P, back); scattered[P.job] = 1; }
+    HIP_TRY(G.down.finish(G.coef.p, back, G.s));
+    for (int ji : G.jobs) ++ndone[ji];
+    // the group's stream work is complete: recycle its device arenas and download staging now, so
+    // that memory in flight is bounded by the window below and not by the size of the batch.  The
+    // upload staging of a band job stays (it is the restore copy): that is one image's worth.
+    G.release_transients(/*keep_stage=*/banded);
+    return QS_HIP_OK;
+  };
+
+  // At most kWindow groups are in flight (about 200k blocks each: ~40 MiB of device memory and
+  // ~50 MiB of pinned staging per group).
+  static const size_t kWindow = env_size("QS_HIP_GROUP_WINDOW", 6);
+  auto pump = [&]() -> int {
+    std::deque<FGroup*> inflight;
+    for (FGroup& G : groups) {
+      if (inflight.size() >= kWindow) {
+        if (int r = drain_group(*inflight.front())) return r;
+        inflight.pop_front();
+      }
+      if (int r = enqueue(G)) return r;
+      inflight.push_back(&G);
+    }
+    t_enq = wall_ms();
+    for (FGroup* G : inflight)
+      if (int r = drain_group(*G)) return r;
+    for (FGroup* G : held) {
+      std::vector<Piece> back;
+      for (const FPlane& P : G->planes) if (!bad_job[P.job]) result_pieces(P, back);
+      HIP_TRY(G->down.finish(G->coef.p, back, G->s));
+      for (int ji : G->jobs) ++ndone[ji];
+    }
+    return QS_HIP_OK;
+  };
+  // the caller's rows of job ji <- the original input kept in the pinned upload staging
+  auto restore_job = [&](int ji) {
+    for (FGroup& G : groups)
+      for (const FPlane& P : G.planes)
+        if (P.job == ji && G.stage.p) {
+          std::vector<Piece> pcs;
+          result_pieces(P, pcs);
+          for (const Piece& pc : pcs) memcpy(pc.host, static_cast<const char*>(G.stage.p) + pc.off, pc.len);
+        }
+  };
+  if (int r = pump()) {
+    // Error exit (device out of memory, HIP failure) with groups in flight.  A banded job is scattered
+    // band by band, so some of its rows may already hold results while the call reports a failure:
+    // "image left untouched" must hold for callers that ignore the return value, as the reference's
+    // applications do.  Wait for everything queued, then either finish a job whose every group came
+    // back (its result is complete and checked) or put the original rows back.
+    for (auto& x : lease.p->s) (void)hipStreamSynchronize(x);
+    for (int ji : which) {
+      if (!scattered[ji]) continue;
+      if (!bad_job[ji] && ndone[ji] == ngroups[ji]) {
+        results[ji] = 0;
+        for (int ci = 0; ci < jobs[ji]->ncomp; ++ci)
+          for (int i = 0; i < 64; ++i) jobs[ji]->quant[ci][i] = 1;
+      } else {
+        restore_job(ji);
+      }
+    }
+    return r;
+  }
+  std::vector<int> rerun;
+  for (int ji : which) {
+    if (!bad_job[ji]) { results[ji] = 0; continue; }
+    rerun.push_back(ji);
+    if (scattered[ji]) restore_job(ji);                      // (otherwise the host input is still untouched)
+  }
+  if (trace_on())
+    fprintf(stderr, "qs_hip trace: fused  %zu job(s) in %zu group(s)  enqueue %.2f ms  drain+download %.2f ms  (%zu re-run)\n",
+            which.size(), groups.size(), t_enq - t_start, wall_ms() - t_enq, rerun.size());
+  for (int ji : which) {
+    if (bad_job[ji]) continue;
+    for (int ci = 0; ci < jobs[ji]->ncomp; ++ci)           // reference :2851-2859
+      for (int i = 0; i < 64; ++i) jobs[ji]->quant[ci][i] = 1;
+  }
+  const double t_clear = wall_ms();
+  groups.clear();                                            // give the arenas back before the re-runs allocate
+  if (trace_on()) fprintf(stderr, "qs_hip trace: fused  release %.2f ms\n", wall_ms() - t_clear);
+  for (int ji : rerun)
+    results[ji] = run_job(jobs[ji], flags, niter, 0, nullptr, nullptr, /*eager=*/false);
+  return QS_HIP_OK;
+}

@@ -1,5 +1,8 @@
-// qs_jobint.h -- what the translation units of the job layer share (qs_job.cpp: single-device
-// routes and the C entry points; qs_shard.cpp: the multi-device route).  Not part of the ABI.
+// qs_jobint.h -- what the translation units of the job layer share.  Not part of the ABI.
+//   qs_job.cpp    entry points, validation / early-outs, the general per-component route (run_job), prewarm
+//   qs_fused.cpp  the plane-set route (independent components; very large planes as pipelined bands)
+//   qs_shard.cpp  one job over several devices (bands + halo rows pulled with peer copies)
+//   qs_batch.cpp  qs_hip_do_quantsmooth_batch (many jobs per call; coupled groups)
 #pragma once
 #include <vector>
 
@@ -38,6 +41,15 @@ struct RowScope {
 // general route on the current device (qs_job.cpp)
 int run_job(qs_hip_job* job, int flags, int niter, int progprec,
             qs_hip_progress_fn progress, void* userdata, bool eager);
+
+// plane-set route (qs_fused.cpp): jobs[which[*]] are fusable (job_fusable); results[ji] = what
+// qs_hip_do_quantsmooth would have returned for that job.  Returns 0, or < 0 when the route failed (a job whose
+// rows had already been written is then either complete, results[ji] == 0, or restored to its input).
+int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int flags, int niter, int* results);
+// validation and the reference's early-outs (1: work to do, 0: finished with result 0, < 0: bad job), and
+// the single-job dispatcher behind qs_hip_do_quantsmooth (qs_job.cpp)
+int prepare_job(qs_hip_job* job, int flags, int* niter);
+int do_quantsmooth_impl(qs_hip_job* job, int flags, int niter, int progprec, qs_hip_progress_fn progress, void* userdata);
 
 // multi-device route (qs_shard.cpp).  `devices`: HIP ordinals, one entry per band; an ordinal
 // may repeat (several logical devices on one GPU: how the route is tested on a one-GPU box).

@@ -12,6 +12,41 @@ static int check_plane_args(const void* a, const void* b, int wblk, int hblk, co
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// band arithmetic: ONE definition for the in-process multi-GPU route (qs_shard.cpp: peer copies) and the
+// one-process-per-GPU driver (bands.py: RCCL send/recv).  What differs between the two is the transport.
+
+extern "C" int qs_hip_band_rows(int hblk, int nbands, int band, int align, int* row0, int* row1) {
+  if (hblk < 0 || nbands < 1 || band < 0 || band >= nbands || align < 1 || !row0 || !row1)
+    return qs_fail(QS_HIP_EINVAL, "qs_hip_band_rows: bad argument");
+  const long long units = ((long long)hblk + align - 1) / align;          // band edges on multiples of `align` block rows
+  const long long a = units * band / nbands * align, b = units * (band + 1) / nbands * align;
+  *row0 = (int)(a < hblk ? a : hblk);
+  *row1 = (int)(b < hblk ? b : hblk);
+  return QS_HIP_OK;
+}
+
+extern "C" int qs_hip_colour_band_rows(int hblk_luma, int hblk_chroma, int v_samp, int nbands, int band,
+                                       int* y0, int* y1, int* c0, int* c1) {
+  if (v_samp < 1 || !y0 || !y1 || !c0 || !c1) return qs_fail(QS_HIP_EINVAL, "qs_hip_colour_band_rows: bad argument");
+  if (int r = qs_hip_band_rows(hblk_chroma, nbands, band, 1, c0, c1)) return r;   // cut on chroma block rows
+  const long long a = (long long)*c0 * v_samp, b = (long long)*c1 * v_samp;        // luma: the same image rows
+  *y0 = (int)(a < hblk_luma ? a : hblk_luma);
+  *y1 = band == nbands - 1 ? hblk_luma : (int)(b < hblk_luma ? b : hblk_luma);
+  return QS_HIP_OK;
+}
+
+extern "C" int qs_hip_band_halo_rows(int wblk, int hblk, size_t* send_top, size_t* send_bot,
+                                     size_t* recv_top, size_t* recv_bot, size_t* nbytes) {
+  if (wblk <= 0 || hblk <= 0) return qs_fail(QS_HIP_EINVAL, "qs_hip_band_halo_rows: bad plane size");
+  if (send_top) *send_top = qs_hip_plane_row_offset(wblk, 0);               // first pixel row -> the band above
+  if (send_bot) *send_bot = qs_hip_plane_row_offset(wblk, hblk * 8 - 1);    // last pixel row  -> the band below
+  if (recv_top) *recv_top = qs_hip_plane_row_offset(wblk, -1);              // apron rows: what the neighbours sent
+  if (recv_bot) *recv_bot = qs_hip_plane_row_offset(wblk, hblk * 8);
+  if (nbytes) *nbytes = qs_hip_plane_pitch(wblk);                           // a whole row, apron columns included
+  return QS_HIP_OK;
+}
+
 static int launch_status(const char* who) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return qs_fail(QS_HIP_ENODEV, "%s: launch failed: %s", who, hipGetErrorString(e));

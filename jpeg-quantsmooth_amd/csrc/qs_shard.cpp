@@ -33,10 +33,9 @@ using namespace qsj;
 
 namespace {
 
-// block rows [r0, r1) of band `d` of `n` (the arithmetic of bands.py: band_rows)
+// block rows [r0, r1) of band `d` of `n`: the exported definition (qs_planes.cpp), shared with bands.py
 static void band_rows(int hblk, int n, int d, int& r0, int& r1) {
-  r0 = (int)((long long)hblk * d / n);
-  r1 = (int)((long long)hblk * (d + 1) / n);
+  (void)qs_hip_band_rows(hblk, n, d, 1, &r0, &r1);
 }
 
 struct BandPlane {       // one component's band on one device
@@ -142,16 +141,19 @@ static int exchange(Bands& bands, int nplanes, PlaneFn plane) {
     for (int k = 0; k < nplanes; ++k) {
       uint8_t *mine, *theirs; int wb, hb, wb2, hb2;
       if (!plane((int)d, k, &mine, &wb, &hb)) continue;
-      const size_t pitch = (size_t)qs_plane_pitch(wb);
+      size_t recv_top, recv_bot, pitch, their_top, their_bot;
+      (void)qs_hip_band_halo_rows(wb, hb, nullptr, nullptr, &recv_top, &recv_bot, &pitch);
       if (d > 0 && plane((int)d - 1, k, &theirs, &wb2, &hb2)) {
         Band& U = bands.b[d - 1];
+        (void)qs_hip_band_halo_rows(wb2, hb2, nullptr, &their_bot, nullptr, nullptr, nullptr);
         if (!wait_up) { HIP_TRY(hipStreamWaitEvent(B.s, U.evA, 0)); wait_up = true; }
-        HIP_TRY(pull(B, mine + qs_hip_plane_row_offset(wb, -1), U, theirs + qs_hip_plane_row_offset(wb2, hb2 * 8 - 1), pitch));
+        HIP_TRY(pull(B, mine + recv_top, U, theirs + their_bot, pitch));
       }
       if (d + 1 < n && plane((int)d + 1, k, &theirs, &wb2, &hb2)) {
         Band& L = bands.b[d + 1];
+        (void)qs_hip_band_halo_rows(wb2, hb2, &their_top, nullptr, nullptr, nullptr, nullptr);
         if (!wait_dn) { HIP_TRY(hipStreamWaitEvent(B.s, L.evA, 0)); wait_dn = true; }
-        HIP_TRY(pull(B, mine + qs_hip_plane_row_offset(wb, hb * 8), L, theirs + qs_hip_plane_row_offset(wb2, 0), pitch));
+        HIP_TRY(pull(B, mine + recv_bot, L, theirs + their_top, pitch));
       }
     }
   }
@@ -366,9 +368,8 @@ static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::
 
   for (int d = 0; d < n; ++d) {
     Band& B = bands.b[d];
-    int c0, c1;
-    band_rows(hbc, n, d, c0, c1);
-    const int y0 = std::min(c0 * hs, hby), y1 = d == n - 1 ? hby : std::min(c1 * hs, hby);
+    int c0, c1, y0, y1;
+    if (int r = qs_hip_colour_band_rows(hby, hbc, hs, n, d, &y0, &y1, &c0, &c1)) return r;
     for (int ci = 0; ci < 3; ++ci) {
       BandPlane P;
       P.ci = ci; P.wb = job->wblk[ci];

@@ -39,13 +39,33 @@ int main(int argc, char** argv) {
     PHASE("hipGetDeviceCount", (void)hipGetDeviceCount(&n));
     PHASE("hipSetDevice(0) + hipFree(0) (context)", { (void)hipSetDevice(0); (void)hipFree(nullptr); });
     hipStream_t s[3];
-    PHASE("3 x hipStreamCreateWithFlags", for (int i = 0; i < 3; ++i) (void)hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
+    PHASE("hipStreamCreateWithFlags #1 (device context)", (void)hipStreamCreateWithFlags(&s[0], hipStreamNonBlocking));
+    PHASE("hipStreamCreateWithFlags #2", (void)hipStreamCreateWithFlags(&s[1], hipStreamNonBlocking));
+    PHASE("hipStreamCreateWithFlags #3", (void)hipStreamCreateWithFlags(&s[2], hipStreamNonBlocking));
     void* hp = nullptr; void* dp = nullptr;
     PHASE("hipHostMalloc 8 MiB (portable)", (void)hipHostMalloc(&hp, 8 << 20, hipHostMallocPortable));
     PHASE("hipHostMalloc 8 MiB again", { void* q = nullptr; (void)hipHostMalloc(&q, 8 << 20, hipHostMallocPortable); (void)hipHostFree(q); });
     PHASE("hipMalloc 8 MiB", (void)hipMalloc(&dp, 8 << 20));
     PHASE("hipMalloc 128 MiB", { void* q = nullptr; (void)hipMalloc(&q, 128 << 20); (void)hipFree(q); });
     PHASE("hipMemcpy H2D 8 MiB pinned", (void)hipMemcpy(dp, hp, 8 << 20, hipMemcpyHostToDevice));
+    PHASE("hipMemcpy H2D 8 MiB pinned again", (void)hipMemcpy(dp, hp, 8 << 20, hipMemcpyHostToDevice));
+    {
+      void* big = nullptr; void* dbig = nullptr; void* pin = nullptr;
+      const size_t n = (size_t)128 << 20;
+      (void)hipMalloc(&dbig, n);
+      PHASE("malloc + touch 128 MiB (pageable)", { big = malloc(n); memset(big, 1, n); });
+      PHASE("hipMemcpy H2D 128 MiB pageable", (void)hipMemcpy(dbig, big, n, hipMemcpyHostToDevice));
+      PHASE("hipMemcpy D2H 128 MiB pageable", (void)hipMemcpy(big, dbig, n, hipMemcpyDeviceToHost));
+      PHASE("hipHostRegister 128 MiB", (void)hipHostRegister(big, n, hipHostRegisterPortable));
+      PHASE("hipMemcpy H2D 128 MiB registered", (void)hipMemcpy(dbig, big, n, hipMemcpyHostToDevice));
+      PHASE("hipMemcpy D2H 128 MiB registered", (void)hipMemcpy(big, dbig, n, hipMemcpyDeviceToHost));
+      PHASE("hipHostUnregister 128 MiB", (void)hipHostUnregister(big));
+      PHASE("hipHostMalloc 128 MiB (portable)", (void)hipHostMalloc(&pin, n, hipHostMallocPortable));
+      PHASE("memcpy 128 MiB pageable -> pinned (1 thread)", memcpy(pin, big, n));
+      PHASE("hipMemcpy H2D 128 MiB pinned", (void)hipMemcpy(dbig, pin, n, hipMemcpyHostToDevice));
+      PHASE("hipHostFree 128 MiB", (void)hipHostFree(pin));
+      free(big); (void)hipFree(dbig);
+    }
     (void)hipHostFree(hp); (void)hipFree(dp);
     for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(s[i]);
   }
@@ -62,6 +82,13 @@ int main(int argc, char** argv) {
     coef[ci].resize((size_t)job.wblk[ci] * job.hblk[ci] * 64);
     fill(coef[ci], 17u + ci);
     job.coef[ci] = coef[ci].data();
+  }
+  if (!skip_runtime) {
+    // first launch of a kernel of the product library: code-object load
+    void* d = nullptr; (void)hipMalloc(&d, 1 << 20); (void)hipMemset(d, 0, 1 << 20);
+    PHASE("first kernel of libjpegqs_hip (code object load)", { (void)qs_hip_clamp_plane((int16_t*)d, 8, 8, nullptr); (void)hipDeviceSynchronize(); });
+    PHASE("second kernel launch + sync", { (void)qs_hip_clamp_plane((int16_t*)d, 8, 8, nullptr); (void)hipDeviceSynchronize(); });
+    (void)hipFree(d);
   }
   for (int rep = 0; rep < 4; ++rep) {
     qs_hip_job j = job;
