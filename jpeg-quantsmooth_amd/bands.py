@@ -21,14 +21,25 @@ from __future__ import annotations
 from dataclasses import dataclass
 
 
+_LIB = None
+
+
+def _lib():
+    """the product library: the band arithmetic below is ITS definition (csrc/qs_planes.cpp:
+    qs_hip_band_rows / qs_hip_colour_band_rows / qs_hip_band_halo_rows), shared with the in-process
+    multi-GPU route csrc/qs_shard.cpp -- this driver only adds the transport (torch.distributed)"""
+    global _LIB
+    if _LIB is None:
+        from .hipqs import HipQS
+        _LIB = HipQS()
+    return _LIB
+
+
 def band_rows(hblk: int, world: int, rank: int, align: int = 1):
     """block rows [r0, r1) owned by `rank`; band edges fall on multiples of
     `align` block rows (2 for the luma plane of a 4:2:0 image so that chroma
-    bands line up with luma bands)."""
-    units = -(-hblk // align)
-    r0 = min(hblk, (units * rank // world) * align)
-    r1 = min(hblk, (units * (rank + 1) // world) * align)
-    return r0, r1
+    bands line up with luma bands).  C: qs_hip_band_rows."""
+    return _lib().band_rows(hblk, world, rank, align)
 
 
 @dataclass
@@ -155,11 +166,12 @@ def exchange_halo_packed(hip, planes2d, wblk: int, hblk: int, topo: BandTopology
     every plane is the strided view planes2d[:, off(y) : off(y) + pitch]; it is packed into a contiguous
     [batch, pitch] buffer by one copy kernel, sent, and the received buffer lands in the apron rows by one
     strided copy.  hostcopy: stage through host memory (gloo)."""
-    pitch = hip.plane_pitch(wblk)
+    send_top, send_bot, recv_top, recv_bot, pitch = hip.band_halo_rows(wblk, hblk)   # the C definition
     h = hblk * 8
+    offs = {0: send_top, h - 1: send_bot, -1: recv_top, h: recv_bot}
 
     def view(y):
-        o = hip.plane_row_offset(wblk, y)
+        o = offs[y]
         return planes2d[:, o:o + pitch]
     ops, recvs = [], []
     for nbr, src_y, dst_y in ((topo.up, 0, -1), (topo.down, h - 1, h)):
@@ -303,6 +315,13 @@ class HipBandEngine(BandEngine):
                                  self.wblk, self.hblk, row0, row1, self.flags, self.luma, final_clamp, self._s())
 
     def row(self, y):
+        """the four rows of the halo exchange come from the C definition (qs_hip_band_halo_rows); any
+        other row (tests) from the plane geometry"""
+        h = self.hblk * 8
+        if y in (0, h - 1, -1, h):
+            st, sb, rt, rb, n = self.hip.band_halo_rows(self.wblk, self.hblk)
+            o = {0: st, h - 1: sb, -1: rt, h: rb}[y]          # (hblk * 8 - 1 == 0 cannot happen: a band has >= 8 pixel rows)
+            return self.plane[o:o + n]
         o = self.hip.plane_row_offset(self.wblk, y)
         return self.plane[o:o + self.pitch]
 
@@ -352,6 +371,11 @@ class PlaneRows:
         self.pitch = hip.plane_pitch(wblk)
 
     def row(self, y):
+        h = self.hblk * 8
+        if y in (0, h - 1, -1, h):
+            st, sb, rt, rb, n = self.hip.band_halo_rows(self.wblk, self.hblk)
+            o = {0: st, h - 1: sb, -1: rt, h: rb}[y]
+            return self.t[o:o + n]
         o = self.hip.plane_row_offset(self.wblk, y)
         return self.t[o:o + self.pitch]
 
@@ -529,12 +553,8 @@ def exchange_rows_dist_hostcopy(rows: PlaneRows, topo: BandTopology, dist) -> No
 
 
 def colour_band_split(hblk_y, hblk_c, vs, world):
-    """[(luma r0, r1, chroma r0, r1)] per rank; cut on chroma block rows"""
-    out = []
-    for r in range(world):
-        c0, c1 = band_rows(hblk_c, world, r)
-        out.append((min(c0 * vs, hblk_y), min(c1 * vs, hblk_y), c0, c1))
-    return out
+    """[(luma r0, r1, chroma r0, r1)] per rank; cut on chroma block rows.  C: qs_hip_colour_band_rows."""
+    return [_lib().colour_band_rows(hblk_y, hblk_c, vs, world, r) for r in range(world)]
 
 
 def run_colour_band_dist(band: ColourBand, dist) -> None:

@@ -77,6 +77,9 @@ ABI = {
                                           PROGRESS_FN, C.c_void_p]),
     "qs_hip_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "qs_hip_do_quantsmooth_sharded": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "qs_hip_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "qs_hip_colour_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4),
+    "qs_hip_band_halo_rows": (C.c_int, [C.c_int, C.c_int] + [C.POINTER(C.c_size_t)] * 5),
     "qs_hip_free": (None, [C.c_void_p]),
     "qs_hip_release_cache": (None, []),
     "qs_hip_device_count": (C.c_int, []),
@@ -188,6 +191,23 @@ class HipQS:
         out = np.zeros(self.consts_bytes(), dtype=np.uint8)
         self._check(self.lib.qs_hip_consts_build(out.ctypes.data, q.ctypes.data_as(C.POINTER(C.c_uint16)), flags))
         return out
+
+    # -- band arithmetic (one definition, shared with csrc/qs_shard.cpp) ----------
+    def band_rows(self, hblk: int, nbands: int, band: int, align: int = 1):
+        r0, r1 = C.c_int(0), C.c_int(0)
+        self._check(self.lib.qs_hip_band_rows(hblk, nbands, band, align, C.byref(r0), C.byref(r1)))
+        return r0.value, r1.value
+
+    def colour_band_rows(self, hblk_luma: int, hblk_chroma: int, v_samp: int, nbands: int, band: int):
+        v = [C.c_int(0) for _ in range(4)]
+        self._check(self.lib.qs_hip_colour_band_rows(hblk_luma, hblk_chroma, v_samp, nbands, band, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def band_halo_rows(self, wblk: int, hblk: int):
+        """-> (send_top, send_bot, recv_top, recv_bot, nbytes): byte offsets inside a band's pixel plane"""
+        v = [C.c_size_t(0) for _ in range(5)]
+        self._check(self.lib.qs_hip_band_halo_rows(wblk, hblk, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     # -- job layer -------------------------------------------------------------
     @staticmethod
