@@ -125,6 +125,15 @@ int qs_hip_colour_band_rows(int hblk_luma, int hblk_chroma, int v_samp, int nban
 int qs_hip_band_halo_rows(int wblk, int hblk, size_t *send_top, size_t *send_bot,
 		size_t *recv_top, size_t *recv_bot, size_t *nbytes);
 
+/* Optional, returns at once: bring the GPU side up IN THE BACKGROUND while the caller is still busy with something
+ * else -- typically libjpeg's entropy decoding between jpeg_read_header() and jpeg_read_coefficients().  A fresh
+ * process otherwise pays for the HIP runtime, the device context, the code object and the pinned staging buffers
+ * inside its first do_quantsmooth (about 0.1 s for a full-HD image, 0.2-0.3 s for 8192 x 8192).  geometry: a job
+ * whose ncomp / colorspace / wblk / hblk / hsamp / vsamp / has_quant / quant fields describe the coming call (coef
+ * pointers are ignored; quant tables only decide the route), or NULL to start the runtime only.  The first job-layer
+ * call waits for a prewarm still in flight.  Not in the reference API. */
+int qs_hip_prewarm(const qs_hip_job *geometry, int flags, int niter);
+
 void qs_hip_free(void *p);
 /* the job layer keeps freed device buffers (up to 6 GiB per device), pinned staging buffers (up
  * to 2 GiB) and HIP streams in process-wide caches, each entry tied to the device it was created

@@ -74,6 +74,14 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 JPEGQS_ATTR
 int jpegqs_hip_backend_status(void);
 
+/* Not in the reference: bring the GPU side up in the background while libjpeg is still decoding the file.
+ * jpegqs_hip_prewarm(NULL, NULL) first thing in main() starts the HIP runtime; called again after
+ * jpeg_read_header() with the options of the coming do_quantsmooth() it also sizes the transfer buffers.
+ * Optional -- do_quantsmooth() works without it, the first call in a process is just slower by 0.1-0.3 s.
+ * jpegqs_start_decompress() calls it by itself. */
+JPEGQS_ATTR
+void jpegqs_hip_prewarm(j_decompress_ptr cinfo, jpegqs_control_t *opts);
+
 #ifndef TRANSCODE_ONLY
 /* Decode-mode wrappers: replace jpeg_start_decompress()/jpeg_finish_decompress()
  * so that jpeg_read_scanlines() delivers the smoothed image. */

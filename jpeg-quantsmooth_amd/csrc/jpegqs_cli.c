@@ -105,6 +105,10 @@ int main(int argc, char **argv) {
 		opts.threads = threads;
 	}
 
+	/* the HIP runtime starts up on a background thread while the file is opened and entropy-decoded
+	 * (not for --niter 0 without upsampling: that is a plain transcode and needs no device) */
+	if (opts.niter > 0 || (opts.flags & JPEGQS_UPSAMPLE_UV)) jpegqs_hip_prewarm(NULL, NULL);
+
 	src.err = jpeg_std_error(&src_err);
 	jpeg_create_decompress(&src);
 	dst.err = jpeg_std_error(&dst_err);
@@ -122,6 +126,7 @@ int main(int argc, char **argv) {
 	if (copy > 1) for (i = 0; i < 16; i++) jpeg_save_markers(&src, JPEG_APP0 + i, 0xFFFF);
 
 	(void)jpeg_read_header(&src, TRUE);
+	jpegqs_hip_prewarm(&src, &opts);      /* geometry known: the transfer buffers are set up during the decode */
 	coefs = jpeg_read_coefficients(&src);
 	/* The reference ignores the return value (its do_quantsmooth cannot fail, and a cancelled or
 	 * rejected run still leaves a decodable image, quantsmooth.c:550).  The GPU back end can fail:

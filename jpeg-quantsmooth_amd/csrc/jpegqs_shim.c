@@ -59,6 +59,32 @@ static void release_parked(void) {
 	for (j = 0; j < QS_HIP_MAXC; j++) if (qs_copy[j]) { free(qs_copy[j]); qs_copy[j] = NULL; }
 }
 
+/* Not in the reference: start the GPU side in the background while libjpeg is still busy with the file
+ * (qs_hip_prewarm, include/jpegqs_hip.h).  cinfo == NULL: the runtime only (call it first thing in main());
+ * after jpeg_read_header(): also the transfer buffers for this image.  Returns at once; never fails loudly. */
+void jpegqs_hip_prewarm(j_decompress_ptr cinfo, jpegqs_control_t *opts) {
+	qs_hip_job g;
+	int ci, i;
+	if (!cinfo || !opts) { (void)qs_hip_prewarm(NULL, 0, 0); return; }
+	if (opts->niter <= 0 && !(opts->flags & JPEGQS_UPSAMPLE_UV)) return;   /* the early-out of reference :2458 needs no device */
+	if (cinfo->num_components < 1 || cinfo->num_components > QS_HIP_MAXC) return;
+	memset(&g, 0, sizeof(g));
+	g.ncomp = cinfo->num_components;
+	g.colorspace = (int)cinfo->jpeg_color_space;
+	g.image_width = (int)cinfo->image_width;
+	g.image_height = (int)cinfo->image_height;
+	for (ci = 0; ci < g.ncomp; ci++) {
+		jpeg_component_info *comp = cinfo->comp_info + ci;
+		JQUANT_TBL *tbl = comp->quant_table;
+		if (!tbl && comp->quant_tbl_no >= 0 && comp->quant_tbl_no < NUM_QUANT_TBLS) tbl = cinfo->quant_tbl_ptrs[comp->quant_tbl_no];
+		g.wblk[ci] = (int)comp->width_in_blocks; g.hblk[ci] = (int)comp->height_in_blocks;
+		g.hsamp[ci] = comp->h_samp_factor; g.vsamp[ci] = comp->v_samp_factor;
+		g.has_quant[ci] = tbl != NULL;
+		if (tbl) for (i = 0; i < DCTSIZE2; i++) g.quant[ci][i] = tbl->quantval[i];
+	}
+	(void)qs_hip_prewarm(&g, opts->flags & JPEGQS_FLAGS_MASK, opts->niter);
+}
+
 static double now_ms(void) {
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -306,6 +332,7 @@ boolean jpegqs_start_decompress(j_decompress_ptr cinfo, jpegqs_control_t *opts) 
 	boolean ret;
 	int use_qs = opts->niter > 0 || (opts->flags & JPEGQS_UPSAMPLE_UV);
 	if (use_qs) cinfo->buffered_image = TRUE;
+	if (use_qs) jpegqs_hip_prewarm(cinfo, opts);   /* the GPU side comes up while libjpeg reads the scans */
 	ret = jpeg_start_decompress(cinfo);
 	if (use_qs) {
 		while (!jpeg_input_complete(cinfo)) {

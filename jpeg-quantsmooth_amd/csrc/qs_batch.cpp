@@ -320,6 +320,7 @@ static int do_quantsmooth_batch_impl(qs_hip_job* const* jobs, int njobs, int fla
     (fuse ? fused : single).push_back(j);
   }
   if (fused.empty() && single.empty()) return QS_HIP_OK;
+  warm_wait();
   if (qs_hip_device_count() <= 0)
     return qs_fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
   // Jobs large enough to be cut over several GPUs run alone (run_sharded); everything else is spread

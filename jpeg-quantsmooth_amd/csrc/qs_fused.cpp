@@ -53,21 +53,9 @@ static const size_t kGroupBlocks = (size_t)200 << 10;
 static const size_t kSplitBlocks = env_size("QS_HIP_SPLIT_BLOCKS", (size_t)512 << 10),
                     kBandBlocks = env_size("QS_HIP_BAND_BLOCKS", (size_t)256 << 10);
 
-}  // namespace
-
-int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int flags, int niter, int* results) {
-  StreamLease lease;
-  if (!lease.p) return qs_fail(QS_HIP_ENODEV, "could not create HIP streams: %s", hipGetErrorString(hipGetLastError()));
-  std::list<FGroup> groups;
-  DrainGuard drain{lease.p};
-  const double t_start = wall_ms();
-  double t_enq = t_start;
-
-  // ---- partition into groups (a job never straddles two, unless it is cut into bands)
-  int maxj = 0;
-  for (int ji : which) maxj = std::max(maxj, ji);
-  std::vector<char> split(maxj + 1, 0), bad_job(maxj + 1, 0), scattered(maxj + 1, 0), defer(maxj + 1, 0);
-  std::vector<int> ngroups(maxj + 1, 0), ndone(maxj + 1, 0);   // groups a job's planes live in / groups whose results are back
+// ---- partition into groups (a job never straddles two, unless it is cut into bands)
+static void partition(const qs_hip_job* const* jobs, const std::vector<int>& which, int niter,
+                      std::list<FGroup>& groups, std::vector<char>& split) {
   for (int ji : which) {
     const qs_hip_job* job = jobs[ji];
     size_t jblocks = 0;
@@ -107,13 +95,43 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
                           0, 0, job->hblk[ci]});
   }
   groups.remove_if([](const FGroup& g) { return g.planes.empty(); });   // placeholders left by band jobs
+}
+
+}  // namespace
+
+// the pinned staging sizes a plane-set run of this one job will ask for (upload and download alike): one per group
+void qsj::fused_stage_sizes(const qs_hip_job* job, int niter, std::vector<size_t>& out) {
+  std::list<FGroup> groups;
+  std::vector<char> split(1, 0);
+  const qs_hip_job* one[1] = { job };
+  partition(one, std::vector<int>{0}, niter, groups, split);
+  for (const FGroup& G : groups) {
+    size_t n = 0;
+    for (const FPlane& P : G.planes) n += P.cbytes;
+    out.push_back(n);
+  }
+}
+
+int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int flags, int niter, int* results) {
+  StreamLease lease;
+  if (!lease.p) return qs_fail(QS_HIP_ENODEV, "could not create HIP streams: %s", hipGetErrorString(hipGetLastError()));
+  std::list<FGroup> groups;
+  DrainGuard drain{lease.p};
+  const double t_start = wall_ms();
+  double t_enq = t_start;
+
+  int maxj = 0;
+  for (int ji : which) maxj = std::max(maxj, ji);
+  std::vector<char> split(maxj + 1, 0), bad_job(maxj + 1, 0), scattered(maxj + 1, 0), defer(maxj + 1, 0);
+  std::vector<int> ngroups(maxj + 1, 0), ndone(maxj + 1, 0);   // groups a job's planes live in / groups whose results are back
+  partition(jobs, which, niter, groups, split);
   for (const FGroup& G : groups) for (int ji : G.jobs) ++ngroups[ji];
 
   // ---- per group: upload, niter x (pass A, pass B), status readback, download into pinned memory
   const int diag = (flags & QS_DIAGONALS) != 0;
   size_t gi = 0;
   auto enqueue = [&](FGroup& G) -> int {
-    G.s = lease.p->s[gi++ % 3];
+    G.s = lease.p->get((int)(gi++ % 3));
     const int np = (int)G.planes.size();
     size_t coef_bytes = 0, px_bytes = 0;
     std::vector<const uint16_t*> qtabs;
@@ -241,7 +259,7 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
     // "image left untouched" must hold for callers that ignore the return value, as the reference's
     // applications do.  Wait for everything queued, then either finish a job whose every group came
     // back (its result is complete and checked) or put the original rows back.
-    for (auto& x : lease.p->s) (void)hipStreamSynchronize(x);
+    lease.p->sync_all();
     for (int ji : which) {
       if (!scattered[ji]) continue;
       if (!bad_job[ji] && ndone[ji] == ngroups[ji]) {

@@ -127,7 +127,7 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
 
     // stream: luma (and anything coupled to it) on stream 0; independent
     // components round-robin
-    hipStream_t s = st.s[eager ? ci % nstreams : 0];
+    hipStream_t s = st.get(eager ? ci % nstreams : 0);
     C.stream = s; C.processed = true;
     HIP_TRY(C.coef.alloc(cbytes));
     HIP_TRY(C.cst.alloc(sizeof(QsConsts)));
@@ -255,7 +255,7 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
 
   // ---- everything is enqueued; eager mode reads the range-check flags now
   const double t_enq = wall_ms();
-  for (int i = 0; i < nstreams; ++i) HIP_TRY(hipStreamSynchronize(st.s[i]));
+  for (int i = 0; i < nstreams; ++i) if (st.s[i]) HIP_TRY(hipStreamSynchronize(st.s[i]));
   const double t_done = wall_ms();
   if (eager)
     for (int ci = 0; ci < job->ncomp; ++ci)
@@ -288,7 +288,7 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
     return QS_HIP_OK;
   };
   if (int r = scatter()) {
-    for (int i = 0; i < nstreams; ++i) (void)hipStreamSynchronize(st.s[i]);
+    st.sync_all();
     for (int ci = 0; ci < job->ncomp; ++ci) {
       Comp& C = comp[ci];
       if (!C.processed || !C.stage.p) continue;
@@ -352,6 +352,90 @@ bool qsj::job_fusable(const qs_hip_job* job, int flags) {
   return true;
 }
 
+// ---------------------------------------------------------------------------
+// prewarm: a FRESH process pays ~50 ms for hipInit, ~35 ms for the device context and its first hardware queue,
+// ~16 ms for the first DMA, ~10 ms for the code object and ~15 ms per 64 MiB of pinned staging (tools/cold_phases,
+// profiles/r03*) -- none of it depends on the coefficients, all of it can run while the application is still
+// entropy-decoding the file (libjpeg needs 0.4 s for an 8192^2 image).  qs_hip_prewarm() does it on a detached
+// thread; the first do_quantsmooth waits for that thread instead of repeating its work.
+namespace {
+std::mutex g_warm_mu;
+std::condition_variable g_warm_cv;
+int g_warm_running = 0;                 // prewarm threads at work (guarded by g_warm_mu)
+std::once_flag g_warm_runtime_once;
+
+void warm_runtime() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return; }
+  const double t0 = wall_ms();
+  { StreamLease lease; (void)lease; }                        // device context + first queue, parked in the pool
+  const double t1 = wall_ms();
+  DevBuf d; PinnedBuf h;
+  if (d.alloc(1 << 20) == hipSuccess && h.alloc(1 << 20)) {
+    memset(h.p, 0, 1 << 20);
+    (void)hipMemcpy(d.p, h.p, 1 << 20, hipMemcpyHostToDevice);          // first DMA
+    qs_launch_clamp(d.as<int16_t>(), 64, nullptr);                       // first kernel: loads the code object
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+  }
+  (void)HostPool::get();                                     // helper threads
+  if (trace_on()) fprintf(stderr, "qs_hip trace: prewarm  context+queue %.2f ms  first copy+kernel+helpers %.2f ms\n", t1 - t0, wall_ms() - t1);
+}
+
+void warm_pools(std::vector<size_t> sizes) {
+  const double t0 = wall_ms();
+  std::vector<std::unique_ptr<PinnedBuf>> hold;              // all at once: distinct blocks; released to the pool together
+  size_t total = 0;
+  for (size_t n : sizes) {
+    if (n < kStageMin || total + round_size(n) > ((size_t)2 << 30)) continue;
+    std::unique_ptr<PinnedBuf> b(new PinnedBuf);
+    if (!b->alloc(n)) break;
+    total += b->n;
+    hold.push_back(std::move(b));
+  }
+  if (trace_on()) fprintf(stderr, "qs_hip trace: prewarm  %zu pinned block(s), %.0f MiB: %.2f ms\n", hold.size(), total / 1048576.0, wall_ms() - t0);
+}
+}  // namespace
+
+void qsj::warm_wait() {
+  std::unique_lock<std::mutex> lk(g_warm_mu);
+  g_warm_cv.wait(lk, [] { return g_warm_running == 0; });
+}
+
+extern "C" int qs_hip_prewarm(const qs_hip_job* geometry, int flags, int niter) {
+  try {
+    std::vector<size_t> sizes;
+    if (geometry && geometry->ncomp >= 1 && geometry->ncomp <= QS_HIP_MAXC) {
+      qs_hip_job g = *geometry;
+      int nit = niter;
+      bool ok = true;
+      for (int ci = 0; ci < g.ncomp; ++ci) ok = ok && g.wblk[ci] > 0 && g.hblk[ci] > 0 && (long long)g.wblk[ci] * g.hblk[ci] <= (1ll << 27);
+      if (ok) {
+        nit = nit < 0 ? 0 : nit > 100 ? 100 : nit;
+        std::vector<size_t> one;
+        if (job_fusable(&g, flags)) fused_stage_sizes(&g, nit, one);
+        else for (int ci = 0; ci < g.ncomp; ++ci) one.push_back((size_t)g.wblk[ci] * g.hblk[ci] * 128);
+        for (size_t n : one) { sizes.push_back(n); sizes.push_back(n); }     // upload staging + download staging
+        if ((flags & QS_UPSAMPLE_UV) && job_needs_lowres(&g, flags) && !(g.hsamp[0] == 1 && g.vsamp[0] == 1))
+          for (int k = 0; k < 2; ++k) sizes.push_back((size_t)g.wblk[0] * g.hblk[0] * 128);   // the replacement arrays
+      }
+    }
+    { std::lock_guard<std::mutex> lk(g_warm_mu); ++g_warm_running; }
+    std::thread([sizes]() {
+      try {
+        std::call_once(g_warm_runtime_once, warm_runtime);
+        int n = 0;
+        if (!sizes.empty() && hipGetDeviceCount(&n) == hipSuccess && n > 0) warm_pools(sizes);
+      } catch (...) {}
+      { std::lock_guard<std::mutex> lk(g_warm_mu); --g_warm_running; }
+      g_warm_cv.notify_all();
+    }).detach();
+    return QS_HIP_OK;
+  } catch (...) {
+    return QS_HIP_ENOMEM;                                    // (no thread, no memory: the job will simply start cold)
+  }
+}
+
 extern "C" void qs_hip_release_cache(void) {
   std::lock_guard<std::mutex> lk(g_cache_mu);
   const int cur = current_device();
@@ -393,6 +477,7 @@ int qsj::do_quantsmooth_impl(qs_hip_job* job, int flags, int niter, int progprec
                                qs_hip_progress_fn progress, void* userdata) {
   const int todo = prepare_job(job, flags, &niter);
   if (todo <= 0) return todo;
+  warm_wait();                                                 // a prewarm thread is doing what this call would do first
   if (qs_hip_device_count() <= 0)
     return qs_fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
 
@@ -453,6 +538,7 @@ extern "C" int qs_hip_do_quantsmooth_sharded(qs_hip_job* job, int flags, int nit
     if (!devices || ndev < 1) return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth_sharded: empty device list");
     const int todo = prepare_job(job, flags, &niter);
     if (todo <= 0) return todo;
+    warm_wait();
     if (qs_hip_device_count() <= 0)
       return qs_fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
     int r = run_sharded(job, flags, niter, std::vector<int>(devices, devices + ndev));

@@ -69,7 +69,7 @@ struct Bands {
     for (Band& B : b) {
       if (!B.st) continue;
       (void)hipSetDevice(B.dev);
-      for (auto& x : B.st->s) (void)hipStreamSynchronize(x);
+      B.st->sync_all();
     }
     for (Band& B : b) {
       (void)hipSetDevice(B.dev);

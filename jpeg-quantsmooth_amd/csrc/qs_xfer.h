@@ -397,9 +397,19 @@ inline hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t s
 }
 
 struct Streams {
-  hipStream_t s[3] = {nullptr, nullptr, nullptr};
+  hipStream_t s[3] = {nullptr, nullptr, nullptr};   // s[0] always exists; s[1], s[2] are created on first use (get)
   hipEvent_t luma_done = nullptr;
   int dev = 0;                         // the device the streams belong to
+  // A stream is a hardware queue: creating one costs milliseconds in a fresh process (tools/cold_phases), and a
+  // one-shot job (the CLI) mostly needs one.  Falls back to s[0] if the queue cannot be created.
+  hipStream_t get(int i) {
+    if (!s[i]) {
+      DeviceScope on(dev);
+      if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); s[i] = nullptr; return s[0]; }
+    }
+    return s[i];
+  }
+  void sync_all() { for (auto& x : s) if (x) (void)hipStreamSynchronize(x); }
   ~Streams() {
     DeviceScope on(dev);
     for (auto& x : s) if (x) (void)hipStreamDestroy(x);
@@ -421,8 +431,7 @@ struct StreamLease {     // borrow a ready-made set of streams of the CURRENT de
     Streams* n = new (std::nothrow) Streams;
     if (!n) return;
     n->dev = dev;
-    bool ok = true;
-    for (int i = 0; i < 3 && ok; ++i) ok = hipStreamCreateWithFlags(&n->s[i], hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&n->s[0], hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&n->luma_done, hipEventDisableTiming) == hipSuccess;
     if (!ok) { delete n; return; }
     p = n;
@@ -432,7 +441,7 @@ struct StreamLease {     // borrow a ready-made set of streams of the CURRENT de
   StreamLease(StreamLease&& o) noexcept : p(o.p) { o.p = nullptr; }
   ~StreamLease() {
     if (!p) return;
-    for (auto& x : p->s) (void)hipStreamSynchronize(x);   // nothing of this job may outlive it
+    p->sync_all();                                        // nothing of this job may outlive it
     std::lock_guard<std::mutex> lk(g_cache_mu);
     g_stream_pool.push_back(p);
   }
@@ -442,7 +451,7 @@ struct StreamLease {     // borrow a ready-made set of streams of the CURRENT de
 // buffers it protects (locals are destroyed in reverse order).
 struct DrainGuard {
   Streams* st;
-  ~DrainGuard() { if (st) for (auto& x : st->s) (void)hipStreamSynchronize(x); }
+  ~DrainGuard() { if (st) st->sync_all(); }
 };
 
 }  // namespace qsx

@@ -80,6 +80,7 @@ ABI = {
     "qs_hip_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "qs_hip_colour_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4),
     "qs_hip_band_halo_rows": (C.c_int, [C.c_int, C.c_int] + [C.POINTER(C.c_size_t)] * 5),
+    "qs_hip_prewarm": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int]),
     "qs_hip_free": (None, [C.c_void_p]),
     "qs_hip_release_cache": (None, []),
     "qs_hip_device_count": (C.c_int, []),

@@ -35,7 +35,15 @@ if "avx2" in flags:
     exes.append(("ref avx2+openmp", refdir / "jpegqs_ref_avx2"))
 exes.append(("ref scalar+openmp", refdir / "jpegqs_ref_none"))
 cases = [("gray", size, size, 3), ("gray", size, size, 4), ("rgb420", 1920, 1080, 3), ("rgb420", 1920, 1080, 6), ("rgb420", size // 2, size // 2, 6)]
+usable = len(os.sched_getaffinity(0))
+try:
+    quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+    if quota.isdigit() and int(period) > 0:
+        usable = max(1, min(usable, int(quota) // int(period)))
+except (OSError, ValueError):
+    pass
 made = {}
+print(f"# reference CLIs run with --threads {usable}")
 print(f"# usable cpus: {len(os.sched_getaffinity(0))}, cgroup cpu.max: {Path('/sys/fs/cgroup/cpu.max').read_text().strip() if Path('/sys/fs/cgroup/cpu.max').exists() else '?'}")
 for kind, w, h, q in cases:
     key = (kind, w, h)
@@ -57,7 +65,10 @@ for kind, w, h, q in cases:
         qs, walls = [], []
         for rep in range(repeats if name != "ref scalar+openmp" else 1):
             t0 = time.time()
-            r = subprocess.run([str(exe), "-q", str(q), "-i", "8", str(src), str(dst)], capture_output=True, text=True)
+            # the reference sizes its OpenMP team by the logical CPU count (256 on this box) although the cgroup grants
+            # far fewer cores: give it the usable count, as a user of that box would
+            extra = ["-t", str(usable)] if name.startswith("ref") else []
+            r = subprocess.run([str(exe), "-q", str(q), "-i", "8", *extra, str(src), str(dst)], capture_output=True, text=True)
             walls.append(time.time() - t0)
             m = re.search(r"quantsmooth: ([0-9.]+)ms", r.stderr)
             qs.append(float(m.group(1)) if m else float("nan"))

@@ -38,7 +38,10 @@ for step in "$@"; do
       for i in 1 2 3; do ./tools/cold_phases 1920 1080 3; done > $O/cold_1080p.txt 2>&1
       for i in 1 2 3; do ./tools/cold_phases 8192 8192 1; done > $O/cold_8192.txt 2>&1
       for i in 1 2; do COLD_SKIP_RUNTIME=1 QS_HIP_TRACE=1 ./tools/cold_phases 1920 1080 3; done > $O/cold_1080p_libfirst.txt 2>&1
-      cat $O/cold_1080p.txt | head -20; head -20 $O/cold_8192.txt; head -24 $O/cold_1080p_libfirst.txt ;;
+      for i in 1 2; do COLD_SKIP_RUNTIME=1 QS_HIP_TRACE=1 ./tools/cold_phases 8192 8192 1; done > $O/cold_8192_libfirst.txt 2>&1
+      for ms in 0 20 150; do COLD_SKIP_RUNTIME=1 COLD_PREWARM=$ms QS_HIP_TRACE=1 ./tools/cold_phases 1920 1080 3; done > $O/cold_1080p_prewarm.txt 2>&1
+      for ms in 0 150 400; do COLD_SKIP_RUNTIME=1 COLD_PREWARM=$ms QS_HIP_TRACE=1 ./tools/cold_phases 8192 8192 1; done > $O/cold_8192_prewarm.txt 2>&1
+      head -45 $O/cold_1080p.txt; head -12 $O/cold_8192_libfirst.txt; cat $O/cold_1080p_prewarm.txt $O/cold_8192_prewarm.txt ;;
     cli)
       timeout 1200 python tools/bench_cli.py ${rest:-8192} > $O/bench_cli.txt 2>&1; cat $O/bench_cli.txt ;;
     sizes)
