@@ -75,6 +75,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sweep")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra legs of the luma workload (single-plane latency, smooth input, the product's own multi-GPU route)")
+    ap.add_argument("--input", default="survey", choices=("survey", "smooth"),
+                    help="synthetic image: the SURVEY.md 8d formula (default) or its noise-free, ten times smoother variant")
     ap.add_argument("--verify", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="torch.distributed backend (gloo: functional test of the sharded path)")
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (functional test of the sharded path on a 1-GPU box, with --backend gloo)")
@@ -84,18 +88,22 @@ def parse_args():
     return a
 
 
-def _synth_plane_gpu(torch, pkg, w, h, quant, dev, variant=0, seed=1234, squeeze=False):
+def _synth_plane_gpu(torch, pkg, w, h, quant, dev, variant=0, seed=1234, squeeze=False, smooth=False):
     """int16 [h/8, w/8, 64] quantised coefficients of the synthetic plane (formula of synth.py /
     SURVEY.md 8d), float32 DCT via two small matmuls on the GPU"""
     synth = pkg.synth
     g = torch.Generator(device=dev); g.manual_seed(seed + 7919 * variant)
     x = torch.arange(w, device=dev, dtype=torch.float32)[None, :]
     y = torch.arange(h, device=dev, dtype=torch.float32)[:, None]
-    px, py = 17.0 + 5 * variant, 23.0 + 3 * variant
+    # smooth: the same formula with every period ten times longer and no sensor noise -- large flat / gently shaded
+    # regions, where the reference's need_refresh skips most refresh IDCTs (quantsmooth.h:1407-1409)
+    k = 10 if smooth else 1
+    px, py = (17.0 + 5 * variant) * k, (23.0 + 3 * variant) * k
     img = 128.0 + 60.0 * torch.sin(x / px) + 50.0 * torch.cos(y / py)
-    checker = ((torch.arange(w, device=dev) // (37 + 4 * variant))[None, :] + (torch.arange(h, device=dev) // (29 + 2 * variant))[:, None]) & 1
+    checker = ((torch.arange(w, device=dev) // ((37 + 4 * variant) * k))[None, :] + (torch.arange(h, device=dev) // ((29 + 2 * variant) * k))[:, None]) & 1
     img = img + 40.0 * (checker.float() - 0.5)
-    img = img + torch.randn(h, w, device=dev, generator=g) * 6.0
+    if not smooth:
+        img = img + torch.randn(h, w, device=dev, generator=g) * 6.0
     y0, x0 = h // 5, w // 3
     img[y0:y0 + h // 7, x0:x0 + w // 4] *= 0.45
     img = img.round().clamp(0, 255)
@@ -109,10 +117,10 @@ def _synth_plane_gpu(torch, pkg, w, h, quant, dev, variant=0, seed=1234, squeeze
     return torch.round(c / q).to(torch.int16).reshape(h // 8, w // 8, 64).contiguous()
 
 
-def synth_input_gpu(torch, pkg, size, jpeg_quality, dev):
+def synth_input_gpu(torch, pkg, size, jpeg_quality, dev, smooth=False):
     """luma workload: (coef int16 [hblk, wblk, 64] on the device, quant uint16[64])"""
     quant = pkg.synth.quality_table(pkg.synth.STD_LUMA, jpeg_quality)
-    return _synth_plane_gpu(torch, pkg, size, size, quant, dev), quant
+    return _synth_plane_gpu(torch, pkg, size, size, quant, dev, smooth=smooth), quant
 
 
 def synth_colour_gpu(torch, pkg, size, jpeg_quality, dev):
@@ -233,6 +241,8 @@ def main():
                 args.backend = "gloo"
         if args.backend != "nccl":
             dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a host-only barrier (an RCCL barrier keeps a kernel spinning on every waiting GPU): used while rank 0 runs a leg alone
+    host_group = dist.new_group(backend="gloo") if (world > 1 and args.backend == "nccl") else None
 
     pkg = jpegqs_pkg.load()
     hip = pkg.HipQS()          # raises if the HIP library is missing: no fallback
@@ -244,7 +254,7 @@ def main():
     verify = not args.no_verify
     nsteps = args.steps + args.warmup
     ctx = dict(args=args, torch=torch, dist=dist, pkg=pkg, hip=hip, bands=bands, flags=flags, size=size, world=world,
-               rank=rank, dev=dev, sharded=sharded, verify=verify, nsteps=nsteps)
+               rank=rank, dev=dev, sharded=sharded, verify=verify, nsteps=nsteps, host_group=host_group)
     run = run_colour if colour else run_luma
     res = run(ctx)
 
@@ -281,7 +291,7 @@ def main():
             "timed_region_s": res["elapsed"],
             "config": {"workload": res["workload"] +
                        f", jpegqs --quality {args.quality} (flags={flags}) --niter {args.niter}; input = quantised float32-DCT "
-                       f"coefficients of the synthetic image of SURVEY.md 8d at JPEG quality {args.jpeg_quality} (built on the GPU; not "
+                       f"coefficients of the synthetic image of SURVEY.md 8d{' (smooth variant: periods x10, no noise)' if args.input == 'smooth' else ''} at JPEG quality {args.jpeg_quality} (built on the GPU; not "
                        f"a libjpeg-encoded file, the CPU baseline consumes the same arrays)",
                        "planes_per_step": res["batch"],
                        "sharding": "none" if world == 1 else f"{world} block-row bands, 1-pixel-row halo over "
@@ -304,6 +314,9 @@ def main():
                               "frac": achieved_tf / VALU_PEAK_TFLOPS,
                               "flop_per_block_iter": FLOP_PER_BLOCK_ITER[flags & 1]},
         }
+        for k in ("single_plane_ms", "value_batch1", "planes_identical", "smooth_input", "product_route", "verify_against"):
+            if res.get(k) is not None:
+                out[k] = res[k]
         for k in ("verify_ok", "verify_rows", "verify_detail", "verify_band_edges_ok"):
             if res.get(k) is not None:
                 out[k] = res[k]
@@ -350,7 +363,7 @@ def run_luma(c):
     r0, r1, hblk = topo.r0, topo.r1, topo.hblk
     total_blocks_plane = (hblk_total * wblk) * (world if args.weak else 1)
 
-    full, quant = synth_input_gpu(torch, pkg, size, args.jpeg_quality, dev)
+    full, quant = synth_input_gpu(torch, pkg, size, args.jpeg_quality, dev, smooth=args.input == "smooth")
     pristine = full[r0:r1].contiguous()
     nsteps = c["nsteps"]
     batch = _batch_size(args, nsteps, pristine.numel() * 2)
@@ -439,6 +452,48 @@ def run_luma(c):
     elapsed = _max_over_ranks(torch, dist, world, time.perf_counter() - t0, dev, args.backend)
     assert not any(e.bad_coef() for e in (engs or [eng])), "range check tripped on synthetic input"
     last = work[-1][-1]                                   # the last plane of the last timed step
+    # every plane of the last timed step must be the same result (they had the same input)
+    planes_identical = all(bool(torch.equal(work[-1][0], p)) for p in work[-1][1:])
+
+    # ---- extra legs (not part of `value`) ------------------------------------------------------------------
+    single_plane_ms = value_batch1 = smooth_res = None
+    if engs and not args.no_extras:
+        # (1) ONE plane per step (batch = 1): the latency of a single image and, for N > 1, single-image strong scaling
+        k1 = max(3, min(args.steps, 20))
+        w1 = [pristine.clone() for _ in range(k1 + 2)]
+
+        def one_single(p):
+            engs[0].rebind(p)
+            bands.run_bands_batched_sets(hip, engs[:1], topo, args.niter,
+                                         (lambda: exch_many(engs[:1], 0)) if is_band else (lambda: None))
+        for p in w1[:2]:
+            one_single(p)
+        _fence(torch, dist, world)
+        t1 = time.perf_counter()
+        for p in w1[2:]:
+            one_single(p)
+        _fence(torch, dist, world)
+        e1 = _max_over_ranks(torch, dist, world, time.perf_counter() - t1, dev, args.backend)
+        single_plane_ms = e1 / k1 * 1e3
+        value_batch1 = total_blocks_plane / (e1 / k1)
+        planes_identical = planes_identical and bool(torch.equal(w1[-1], last))
+        del w1
+        # (2) N = 1: the same workload on the smooth variant of the image (what the wave-uniform need_refresh skip is
+        # worth on content that is not sensor noise; the headline input never lets a whole wave skip)
+        if world == 1 and args.input == "survey":
+            sm, _ = synth_input_gpu(torch, pkg, size, args.jpeg_quality, dev, smooth=True)
+            ks = max(2, min(args.steps, 5))
+            ws = [[sm.clone() for _ in range(batch)] for _ in range(ks + 1)]
+            one_step_sharded(ws[0])
+            _fence(torch, dist, world)
+            t2 = time.perf_counter()
+            for st in ws[1:]:
+                one_step_sharded(st)
+            _fence(torch, dist, world)
+            e2 = time.perf_counter() - t2
+            smooth_res = {"value": total_blocks_plane * batch * ks / e2, "unit": "blocks/s", "ms_per_step": e2 / ks * 1e3,
+                          "steps": ks, "input": "SURVEY.md 8d formula with every period x10 and no noise"}
+            del ws, sm
 
     set_launch = engs is not None                         # the timed launches cover all planes of the step
     res = dict(elapsed=elapsed, batch=batch, total_blocks=total_blocks_plane * batch, blocks_per_gpu=hblk * wblk,
@@ -449,7 +504,9 @@ def run_luma(c):
                launches_per_step=args.niter * (-(-batch // 48) if set_launch else batch),
                kern_ms=float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else None,
                kernel_launches=len(ev_pairs),
-               workload=f"{size}x{size} luma plane ({hblk_total * wblk} blocks)")
+               workload=f"{size}x{size} luma plane ({hblk_total * wblk} blocks)",
+               planes_identical=planes_identical, single_plane_ms=single_plane_ms, value_batch1=value_batch1,
+               smooth_input=smooth_res)
     if c["verify"] and c["sharded"]:
         from oracle.oracle import Oracle
         got = last.cpu().numpy()
@@ -461,21 +518,53 @@ def run_luma(c):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         res["verify_band_edges_ok"] = bool(flag.item())
     if c["verify"]:
-        # N = 1: top / middle / bottom of the whole plane.  N > 1: every rank holds one band; rank 0
-        # checks the top rows of the image here and the band edges were checked above.
-        from oracle.oracle import Oracle, RowSource, verify_bands
+        # The checker: the compiled, unmodified reference (oracle/_ref, scalar build, OpenMP) when it travelled with the
+        # tree, the plain-C port otherwise.  N = 1: EVERY block of the plane (the reference does 8192^2 in ~5 s on 16
+        # cores); larger planes and N > 1 (rank 0 holds one band): 16 block rows at the top, middle, bottom / at the top,
+        # the band edges were checked above.
+        from oracle import oracle as om
+        from oracle.oracle import RowSource, verify_bands
         if rank == 0:
+            truth = om.Reference("none") if om.have_ref("none") else om.Oracle()
+            res["verify_against"] = ("compiled reference (oracle/_ref/libqsref_none.so)" if om.have_ref("none")
+                                     else "plain-C port (oracle/libqs_oracle.so)")
             if c["sharded"]:
                 n = min(16, hblk)
                 crop = keep_full[: min(hblk_total, n + args.niter + 1)].cpu().numpy()
-                want = Oracle().do_quantsmooth([crop], [quant], flags, args.niter, threads=0)["coefs"][0][:n]
+                want = truth.do_quantsmooth([crop], [quant], flags, args.niter, threads=0)["coefs"][0][:n]
                 bad = int((last[:n].cpu().numpy() != want).any(axis=2).sum())
                 detail = [dict(where="top", row0=0, row1=n, bad_blocks=bad)]
+            elif hblk_total * wblk <= (1 << 20) + 1:
+                want = truth.do_quantsmooth([keep_full.cpu().numpy()], [quant], flags, args.niter, threads=0)["coefs"][0]
+                bad = int((last.cpu().numpy() != want).any(axis=2).sum())
+                detail = [dict(where="whole plane", row0=0, row1=hblk_total, bad_blocks=bad)]
             else:
-                detail = verify_bands(Oracle(), RowSource(keep_full), quant, flags, args.niter, RowSource(last), rows=16)
+                detail = verify_bands(truth, RowSource(keep_full), quant, flags, args.niter, RowSource(last), rows=16)
             res["verify_detail"] = detail
             res["verify_rows"] = sum(d["row1"] - d["row0"] for d in detail)
-            res["verify_ok"] = all(d["bad_blocks"] == 0 for d in detail)
+            res["verify_ok"] = all(d["bad_blocks"] == 0 for d in detail) and planes_identical
+    # (3) the PRODUCT's own multi-GPU route (csrc/qs_shard.cpp behind qs_hip_do_quantsmooth_sharded: one process, peer
+    # copies) over the same devices, host arrays in and out -- a child process of rank 0 while the other ranks wait on the
+    # host; its JSON is merged as `product_route`
+    if not args.no_extras and not args.weak and size <= 16384:
+        hg = c.get("host_group")
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier(group=hg) if hg is not None else dist.barrier()
+        if rank == 0:
+            import subprocess
+            devs = ",".join(str(d) for d in (range(world) if not args.single_device else [0] * world))
+            cmd = [sys.executable, str(ROOT / "tools" / "bench_product_route.py"), "--devices", devs, "--size", str(size),
+                   "--quality", str(args.quality), "--niter", str(args.niter), "--jpeg-quality", str(args.jpeg_quality)]
+            try:
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                res["product_route"] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-400:]}
+            except Exception as e:  # noqa: BLE001 -- the headline line must not depend on this leg
+                res["product_route"] = {"error": repr(e)[:300]}
+        if world > 1:
+            dist.barrier(group=hg) if hg is not None else dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         host_plane = keep_full.cpu().numpy()
 

@@ -50,6 +50,7 @@ struct Band {            // one (logical) device
   Streams* st = nullptr;                 // leased under `dev`
   hipStream_t s = nullptr;
   hipEvent_t evA = nullptr, evX = nullptr;
+  hipEvent_t evT0 = nullptr, evT1 = nullptr;   // QS_HIP_TRACE only: first pass A .. last pass B on this band's stream
   std::vector<BandPlane> planes;
   DevBuf coef, px, cst, status, aux[8];   // aux: route-specific planes (colour route)
   PinnedBuf stage, hstatus;
@@ -75,6 +76,8 @@ struct Bands {
       (void)hipSetDevice(B.dev);
       if (B.evA) (void)hipEventDestroy(B.evA);
       if (B.evX) (void)hipEventDestroy(B.evX);
+      if (B.evT0) (void)hipEventDestroy(B.evT0);
+      if (B.evT1) (void)hipEventDestroy(B.evT1);
       B.down.reset(); B.down_up[0].reset(); B.down_up[1].reset();
       B.coef.release(); B.px.release(); B.cst.release(); B.status.release();
       for (auto& a : B.aux) a.release();
@@ -100,6 +103,7 @@ static int open_bands(Bands& bands, const std::vector<int>& devices) {
     B.s = B.st->s[0];
     HIP_TRY(hipEventCreateWithFlags(&B.evA, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&B.evX, hipEventDisableTiming));
+    if (trace_on()) { HIP_TRY(hipEventCreate(&B.evT0)); HIP_TRY(hipEventCreate(&B.evT1)); }
   }
   // direct xGMI access between neighbouring devices (without it the runtime stages peer copies
   // through host memory); "already enabled" is not an error
@@ -295,6 +299,7 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
   const double t_up = wall_ms();
 
   const int diag = (flags & QS_DIAGONALS) != 0;
+  if (trace_on()) for (Band& B : bands.b) { HIP_TRY(hipSetDevice(B.dev)); HIP_TRY(hipEventRecord(B.evT0, B.s)); }
   for (int it = 0; it < niter; ++it) {
     for (size_t d = 0; d < bands.b.size(); ++d) {
       Band& B = bands.b[d];
@@ -314,6 +319,7 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
       qs_launch_smooth_set(B.set, diag, it == niter - 1, B.s);
     }
   }
+  if (trace_on()) for (Band& B : bands.b) { HIP_TRY(hipSetDevice(B.dev)); HIP_TRY(hipEventRecord(B.evT1, B.s)); }
   for (Band& B : bands.b) {
     HIP_TRY(hipSetDevice(B.dev));
     HIP_TRY(hipGetLastError());
@@ -336,9 +342,22 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
       host_pieces(job, P.ci, P.r0, P.hb, P.coef_off, back);
     HIP_TRY_RESTORE(B.down.finish(B.coef.p, back, B.s));
   }
-  if (trace_on())
-    fprintf(stderr, "qs_hip trace: sharded(set) %d band(s)  upload+stage %.2f ms  enqueue %.2f ms  drain+scatter %.2f ms\n",
-            n, t_up - t_start, t_enq - t_up, wall_ms() - t_enq);
+  if (trace_on()) {
+    // device time of the iterations per band (kernels + halo pulls + waiting for the neighbours), by HIP events
+    float worst = 0;
+    std::string per;
+    for (Band& B : bands.b) {
+      float ms = 0;
+      (void)hipSetDevice(B.dev);
+      if (hipEventSynchronize(B.evT1) == hipSuccess && hipEventElapsedTime(&ms, B.evT0, B.evT1) == hipSuccess) {
+        worst = std::max(worst, ms);
+        char buf[32]; snprintf(buf, sizeof buf, " %.2f", ms); per += buf;
+      }
+    }
+    fprintf(stderr, "qs_hip trace: sharded(set) %d band(s)  upload+stage %.2f ms  enqueue %.2f ms  drain+scatter %.2f ms  "
+                    "iterations on device: max %.2f ms (per band:%s)\n",
+            n, t_up - t_start, t_enq - t_up, wall_ms() - t_enq, worst, per.c_str());
+  }
   for (int ci = 0; ci < job->ncomp; ++ci)                    // reference :2851-2859
     if (job->has_quant[ci]) for (int i = 0; i < 64; ++i) job->quant[ci][i] = 1;
   return 0;

@@ -224,7 +224,7 @@ def test_plane_rows_exchange_gloo(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--overlap"], ["--backend", "nccl"]])
+@pytest.mark.parametrize("extra", [[], ["--overlap", "--no-extras"], ["--backend", "nccl", "--no-extras"]])
 def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one
     process per rank, band split, comm side stream, overlapped schedule), but on ONE
@@ -246,6 +246,14 @@ def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
     assert d["verify_band_edges_ok"] is True and d["verify_ok"] is True
     if "nccl" in extra:
         assert "RCCL unavailable" in d["config"]["comm_note"] and "gloo" in d["config"]["sharding"]
+    if not extra:
+        # the extra legs: single-plane steps over the same bands, and the product's own route
+        # (qs_hip_do_quantsmooth_sharded over two logical devices) run as a child process of rank 0
+        assert d["single_plane_ms"] > 0 and d["value_batch1"] > 0 and d["planes_identical"] is True
+        pr = d["product_route"]
+        assert pr.get("error") is None, pr
+        assert pr["entry"] == "qs_hip_do_quantsmooth_sharded" and pr["devices"] == [0, 0]
+        assert pr["equals_one_device_result"] is True and pr["verify_ok"] is True
 
 
 @pytest.mark.gpu
