@@ -6,6 +6,7 @@
 #   host            CPU model, cgroup quota, affinity of the GPU box
 #   pytest[:expr]   the GPU suite (-m gpu), optionally restricted with -k expr
 #   bench:<name>:<args...>   python bench.py <args> -> bench_<name>.json (args separated by ',')
+#   benchlib:<name>:<variant>:<args...>  the same on build/variants/libjpegqs_hip_<variant>.so
 #   prof:<name>:<args...>    tools/profile.sh (kernel-trace + PMC passes) of bench.py <args>
 #   variants:<size> tools/bench_variants.py over build/variants/*.so
 #   cold            tools/cold_phases (fresh-process phase times) for 1080p and 8192^2, three runs each
@@ -29,6 +30,9 @@ for step in "$@"; do
     bench)
       name=${rest%%:*}; args=${rest#*:}; [ "$args" = "$rest" ] && args=""
       timeout 900 python bench.py ${args//,/ } > $O/bench_$name.json 2> $O/bench_$name.err; tail -c 1500 $O/bench_$name.json ;;
+    benchlib)   # benchlib:<name>:<variant>:<args>  -- bench.py on build/variants/libjpegqs_hip_<variant>.so
+      name=${rest%%:*}; r2=${rest#*:}; var=${r2%%:*}; args=${r2#*:}; [ "$args" = "$r2" ] && args=""
+      QS_HIP_LIB=$R/build/variants/libjpegqs_hip_$var.so timeout 900 python bench.py ${args//,/ } > $O/bench_$name.json 2> $O/bench_$name.err; tail -c 700 $O/bench_$name.json ;;
     prof)
       name=${rest%%:*}; args=${rest#*:}; [ "$args" = "$rest" ] && args=""
       timeout 1200 bash tools/profile.sh $name ${args//,/ } > $O/prof_$name.log 2>&1; tail -12 $O/prof_$name.log ;;
