@@ -249,6 +249,12 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
     for (int ci = 0; ci < 3; ++ci)
       host_pieces(jobs[which[g]], ci, 0, jobs[which[g]]->hblk[ci], cj[g].coef_off[ci], back);
   }
+  if (!stage.p) {                                            // no restore copy: everything lands before anything is written
+    HIP_TRY(down.land(coef.p, s));
+    for (int g = 0; g < G; ++g)
+      for (int k = 0; k < 2 && cj[g].upsample; ++k)
+        HIP_TRY(down_up_of[(size_t)g * 2 + k]->land(upc.as<char>() + cj[g].upc_off[k], s));
+  }
   if (hipError_t e = down.finish(coef.p, back, s)) {          // a late failure: put the original blocks back
     (void)hipStreamSynchronize(s);
     if (stage.p) for (const Piece& pc : back) memcpy(pc.host, static_cast<const char*>(stage.p) + pc.off, pc.len);

@@ -210,6 +210,7 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
     std::vector<Piece> back;
     for (const FPlane& P : G.planes)
       if (!bad_job[P.job]) { result_pieces(P, back); scattered[P.job] = 1; }
+    if (!G.stage.p) HIP_TRY(G.down.land(G.coef.p, G.s));        // no restore copy: land first, write afterwards
     HIP_TRY(G.down.finish(G.coef.p, back, G.s));
     for (int ji : G.jobs) ++ndone[ji];
     // the group's stream work is complete: recycle its device arenas and download staging now, so
@@ -235,6 +236,7 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
     t_enq = wall_ms();
     for (FGroup* G : inflight)
       if (int r = drain_group(*G)) return r;
+    for (FGroup* G : held) HIP_TRY(G->down.land(G->coef.p, G->s));   // held back = no restore copy: all land, then all are written
     for (FGroup* G : held) {
       std::vector<Piece> back;
       for (const FPlane& P : G->planes) if (!bad_job[P.job]) result_pieces(P, back);

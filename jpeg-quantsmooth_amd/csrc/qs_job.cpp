@@ -266,6 +266,17 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
   // earlier components have been written, their original blocks are put back from the pinned upload
   // staging: a reported failure leaves the image untouched.
   auto scatter = [&]() -> int {
+    // without the pinned upload staging of EVERY component there is nothing to restore from: then everything
+    // lands in library-owned memory first (the only step that can fail) and is copied to the caller afterwards
+    bool have_copy = true;
+    for (int ci = 0; ci < job->ncomp; ++ci) have_copy = have_copy && (!comp[ci].processed || comp[ci].stage.p);
+    if (!have_copy)
+      for (int ci = 0; ci < job->ncomp; ++ci) {
+        Comp& C = comp[ci];
+        if (!C.processed) continue;
+        HIP_TRY(C.down.land(C.coef.p, C.stream));
+        if (C.have_up && !stop) HIP_TRY(C.down_up.land(C.up.p, C.stream));
+      }
     for (int ci = 0; ci < job->ncomp; ++ci) {
       Comp& C = comp[ci];
       if (!C.processed) continue;
@@ -415,7 +426,7 @@ extern "C" int qs_hip_prewarm(const qs_hip_job* geometry, int flags, int niter) 
         std::vector<size_t> one;
         if (job_fusable(&g, flags)) fused_stage_sizes(&g, nit, one);
         else for (int ci = 0; ci < g.ncomp; ++ci) one.push_back((size_t)g.wblk[ci] * g.hblk[ci] * 128);
-        for (size_t n : one) { sizes.push_back(n); sizes.push_back(n); }     // upload staging + download staging
+        for (size_t n : one) sizes.push_back(n);     // the download landing buffers (a first call uploads straight from the caller's memory)
         if ((flags & QS_UPSAMPLE_UV) && job_needs_lowres(&g, flags) && !(g.hsamp[0] == 1 && g.vsamp[0] == 1))
           for (int k = 0; k < 2; ++k) sizes.push_back((size_t)g.wblk[0] * g.hblk[0] * 128);   // the replacement arrays
       }

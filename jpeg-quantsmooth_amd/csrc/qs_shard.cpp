@@ -270,6 +270,20 @@ static void restore_bands(Bands& bands, const qs_hip_job* job) {
 #define HIP_TRY_RESTORE(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { restore_bands(bands, job); \
   return qs_fail(e_ == hipErrorOutOfMemory ? QS_HIP_ENOMEM : QS_HIP_ENODEV, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
 
+// Without the pinned upload staging of EVERY band there is nothing to restore from: then all results land in
+// library-owned memory first (the only step that can fail) and are copied to the caller afterwards.
+static int land_all_if_no_copy(Bands& bands, bool upsample) {
+  bool have_copy = true;
+  for (Band& B : bands.b) have_copy = have_copy && B.stage.p;
+  if (have_copy) return QS_HIP_OK;
+  for (Band& B : bands.b) {
+    HIP_TRY(hipSetDevice(B.dev));
+    HIP_TRY(B.down.land(B.coef.p, B.s));
+    if (upsample) for (int j = 0; j < 2; ++j) HIP_TRY(B.down_up[j].land(B.aux[3 + j].p, B.s));
+  }
+  return QS_HIP_OK;
+}
+
 // ---------------------------------------------------------------------------
 // independent components: one plane set per band
 static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vector<int>& devices) {
@@ -335,6 +349,7 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
   bool bad = false;
   if (int r = read_flags(bands, bad)) return r;
   if (bad) return JOB_RERUN_CAREFUL;                          // host input is still untouched
+  if (int r = land_all_if_no_copy(bands, false)) return r;
   for (Band& B : bands.b) {
     HIP_TRY_RESTORE(hipSetDevice(B.dev));
     std::vector<Piece> back;
@@ -530,6 +545,7 @@ static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::
       if (!up_host[j]) { free(up_host[0]); return qs_fail(QS_HIP_ENOMEM, "out of host memory"); }
     }
   struct UpFree { int16_t** p; bool keep; ~UpFree() { if (!keep) { free(p[0]); free(p[1]); } } } up_free{up_host, false};
+  if (int r = land_all_if_no_copy(bands, upsample)) return r;
   for (Band& B : bands.b) {
     HIP_TRY_RESTORE(hipSetDevice(B.dev));
     std::vector<Piece> back;

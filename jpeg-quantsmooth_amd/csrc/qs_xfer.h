@@ -41,10 +41,14 @@ struct DeviceScope {
   DeviceScope& operator=(const DeviceScope&) = delete;
 };
 
-inline size_t round_size(size_t n) {               // size classes: powers of two from 64 KiB
+// size classes of the pooled buffers: 64 KiB, then eight steps per octave (a request is rounded up by at most
+// 12.5 %; whole powers of two turned a 34 MiB band into a 64 MiB block -- twice the pinning time in a cold process)
+inline size_t round_size(size_t n) {
   size_t c = (size_t)64 << 10;
-  while (c < n) c <<= 1;
-  return c;
+  if (n <= c) return c;
+  while ((c << 1) < n) c <<= 1;                    // c < n <= 2c
+  const size_t step = c >> 3;
+  return c + (n - c + step - 1) / step * step;
 }
 
 // Test hooks (tests/test_gpu_faults.py), live only when the process was started with QS_HIP_TEST_HOOKS=1 (read
@@ -96,10 +100,13 @@ struct DevBuf {
     dev = current_device();                        // allocations belong to the caller's current device
     {
       std::lock_guard<std::mutex> lk(g_cache_mu);
+      size_t best = g_cache.size();                // the smallest free block of [want, 1.25 want] on this device
       for (size_t i = 0; i < g_cache.size(); ++i)
-        if (g_cache[i].n == want && g_cache[i].dev == dev) {
-          p = g_cache[i].p; n = want; g_cache.erase(g_cache.begin() + i); return hipSuccess;
-        }
+        if (g_cache[i].dev == dev && g_cache[i].n >= want && g_cache[i].n <= want + want / 4 &&
+            (best == g_cache.size() || g_cache[i].n < g_cache[best].n)) best = i;
+      if (best < g_cache.size()) {
+        p = g_cache[best].p; n = g_cache[best].n; g_cache.erase(g_cache.begin() + best); return hipSuccess;
+      }
     }
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {                         // make room and retry once
@@ -140,19 +147,54 @@ struct PinnedBuf {
   PinnedBuf& operator=(const PinnedBuf&) = delete;
   ~PinnedBuf() { release(); }
   static std::vector<CacheEntry>& pool() { static std::vector<CacheEntry> v; return v; }   // (inline function: one per library)
-  bool alloc(size_t bytes) {
+  // optional: the caller has a fall-back that costs less than pinning a large block NOW (an upload can go
+  // straight from pageable memory at ~44 GB/s on this platform, pinning costs ~0.18 ms per MiB): a block above
+  // kOptionalMax is then only taken from the pool, and one is pinned in the background for the next call
+  static constexpr size_t kOptionalMax = (size_t)16 << 20;
+  bool alloc(size_t bytes, bool optional = false) {
     release();                                     // (a reused object must not leak the block it holds)
     if (test_fail_pinned()) return false;
     const size_t want = round_size(bytes);
     {
       std::lock_guard<std::mutex> lk(g_cache_mu);
       auto& v = pool();
+      size_t best = v.size();                      // the smallest free block of [want, 1.25 want]
       for (size_t i = 0; i < v.size(); ++i)
-        if (v[i].n == want) { p = v[i].p; n = want; v.erase(v.begin() + i); return true; }
+        if (v[i].n >= want && v[i].n <= want + want / 4 && (best == v.size() || v[i].n < v[best].n)) best = i;
+      if (best < v.size()) { p = v[best].p; n = v[best].n; v.erase(v.begin() + best); return true; }
+    }
+    if (optional && want > kOptionalMax && upload_stage_mode() != 1) {
+      if (upload_stage_mode() == 2) fill_later(want);
+      return false;
     }
     if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
     n = want;
     return true;
+  }
+  // QS_HIP_UPLOAD_STAGE: 1 = always pin upload staging (round-2 behaviour), 0 = never above 16 MiB, unset = from
+  // the pool only, filled in the background
+  static int upload_stage_mode() {
+    static const int m = [] { const char* v = getenv("QS_HIP_UPLOAD_STAGE"); return !v ? 2 : atoi(v) ? 1 : 0; }();
+    return m;
+  }
+  static void fill_later(size_t want) {
+    static std::atomic<int> busy{0};
+    if (busy.fetch_add(1) >= 2) { busy.fetch_sub(1); return; }          // at most two fills at a time
+    const int dev = current_device();
+    try {
+      std::thread([want, dev] {
+        (void)hipSetDevice(dev);
+        void* q = nullptr;
+        if (hipHostMalloc(&q, want, hipHostMallocPortable) == hipSuccess) {
+          std::lock_guard<std::mutex> lk(g_cache_mu);
+          size_t held = 0;
+          for (auto& c : pool()) held += c.n;
+          if (held + want <= ((size_t)2 << 30)) { pool().push_back({q, want, -1}); q = nullptr; }
+        } else (void)hipGetLastError();
+        if (q) (void)hipHostFree(q);
+        busy.fetch_sub(1);
+      }).detach();
+    } catch (...) { busy.fetch_sub(1); }
   }
   void release() {
     if (!p) return;
@@ -295,7 +337,9 @@ inline void copy_item(char* stage, const std::vector<Piece>& pieces, size_t byte
 inline hipError_t upload_pieces(void* dst, const std::vector<Piece>& pieces, size_t bytes, hipStream_t s, PinnedBuf& stage) {
   // small transfers go straight from the caller's memory -- unless they come in many pieces
   // (a row table whose rows are not adjacent): then one staged DMA beats a copy call per row
-  if ((bytes < kStageMin && pieces.size() <= 4) || !stage.alloc(bytes)) {
+  // ... and large ones too while no pinned block of their size is at hand (a cold process): pageable memory goes
+  // up at ~44 GB/s here, pinning 128 MiB costs 23 ms (tools/cold_phases) -- unless they come in many pieces
+  if ((bytes < kStageMin && pieces.size() <= 4) || !stage.alloc(bytes, /*optional=*/pieces.size() <= 16)) {
     for (const Piece& pc : pieces) {
       hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + pc.off, pc.host, pc.len, hipMemcpyHostToDevice, s);
       if (e != hipSuccess) return e;
@@ -318,29 +362,37 @@ inline hipError_t upload_pieces(void* dst, const std::vector<Piece>& pieces, siz
   return err;
 }
 
-// device -> host in two steps.  issue(): the copy into pinned memory is queued on the
-// stream right behind the kernels that produce the data (8 MiB chunks, one event
-// each), no host wait.  finish(): once the caller knows which pieces it wants, the
-// helpers scatter each chunk to the caller's arrays as its event fires.  (Pageable
-// D2H of a few MiB per call runs at 12-17 GB/s here, this path at the DMA rate; and
-// results reach caller memory only after the range-check flags have been seen.)
+// device -> host.  issue(): the copy into pinned memory is queued on the stream right behind the
+// kernels that produce the data (8 MiB chunks, one event each), no host wait.  Then either
+//   finish():          once the caller knows which pieces it wants, the helpers scatter each chunk to the
+//                      caller's arrays as its event fires (DMA of chunk c+1 overlaps the scatter of chunk c).
+//                      A HIP error may surface after some chunks have been written: only for callers that
+//                      can put the original data back (they hold the pinned upload staging copy);
+//   land() + scatter(): first EVERYTHING arrives in library-owned memory (the pinned stage, or a malloc'ed
+//                      buffer when no pinned block was to be had) -- the only step that can fail --, then
+//                      plain host copies into the caller's arrays.  For callers without a restore copy:
+//                      a reported failure must leave the caller's arrays untouched.
+// (Pageable D2H of a few MiB per call runs at 12-17 GB/s here, the staged path at the DMA rate; and results
+// reach caller memory only after the range-check flags have been seen.)
 struct Download {
   PinnedBuf stage;
   std::vector<hipEvent_t> ev;
   size_t bytes = 0;
-  bool staged = false;
+  bool staged = false, landed = false;
+  void* tmp = nullptr;                    // landing buffer of an unstaged download
   Download() = default;
   Download(const Download&) = delete;
   Download& operator=(const Download&) = delete;
   ~Download() { reset(); }
   void reset() {                          // (the copies must have completed)
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-    ev.clear(); stage.release(); bytes = 0; staged = false;
+    ev.clear(); stage.release(); bytes = 0; staged = false; landed = false;
+    free(tmp); tmp = nullptr;
   }
 
   // always_stage: the destination will be many separate pieces (see upload_pieces)
   hipError_t issue(const void* src, size_t nbytes, hipStream_t s, bool always_stage = false) {
-    bytes = nbytes;
+    bytes = nbytes; landed = false;
     staged = nbytes > 0 && (nbytes >= kStageMin || always_stage) && stage.alloc(nbytes);
     if (!staged) return hipSuccess;
     for (size_t c0 = 0; c0 < bytes; c0 += kStageChunk) {
@@ -362,14 +414,40 @@ struct Download {
   // everything queued before issue() on the stream has completed when this returns
   hipError_t wait_first(hipStream_t s) const { return staged ? hipEventSynchronize(ev[0]) : hipStreamSynchronize(s); }
 
+  // all bytes are in library-owned host memory when this returns hipSuccess; nothing of the caller's is touched
+  hipError_t land(const void* src, hipStream_t s) {
+    if (landed) return hipSuccess;
+    hipError_t e = hipSuccess;
+    if (staged) {
+      for (size_t c = 0; c < ev.size() && e == hipSuccess; ++c) e = hipEventSynchronize(ev[c]);
+    } else if (bytes) {
+      tmp = malloc(bytes);
+      if (!tmp) return hipErrorOutOfMemory;
+      e = hipMemcpyAsync(tmp, src, bytes, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+    } else {
+      e = hipStreamSynchronize(s);
+    }
+    if (e == hipSuccess && test_fail_finish()) e = hipErrorUnknown;        // (test hook: a late transfer failure)
+    landed = e == hipSuccess;
+    return e;
+  }
+  // landed bytes -> the caller's pieces: host copies only, cannot fail
+  void scatter(const std::vector<Piece>& pieces) {
+    if (!landed || pieces.empty() || !bytes) return;
+    char* from = static_cast<char*>(staged ? stage.p : tmp);
+    if (bytes < kStageMin) { copy_range(from, pieces, 0, bytes, false); return; }
+    const int nchunks = (int)((bytes + kStageChunk - 1) / kStageChunk);
+    const std::vector<Piece>* pcs = &pieces;
+    const size_t nbytes = bytes;
+    HostPool::wait(HostPool::get().submit(nchunks * kStageThreads, [=](int i) { copy_item(from, *pcs, nbytes, i, false); }));
+  }
+
+  // overlapped form (see above): land-and-scatter chunk by chunk
   hipError_t finish(const void* src, const std::vector<Piece>& pieces, hipStream_t s) {
-    if (!staged) {
-      for (const Piece& pc : pieces) {
-        hipError_t e = hipMemcpyAsync(pc.host, static_cast<const char*>(src) + pc.off, pc.len, hipMemcpyDeviceToHost, s);
-        if (e != hipSuccess) return e;
-      }
-      hipError_t e = hipStreamSynchronize(s);
-      if (e == hipSuccess && test_fail_finish()) e = hipErrorUnknown;
+    if (!staged || landed) {
+      hipError_t e = land(src, s);
+      if (e == hipSuccess) scatter(pieces);
       return e;
     }
     // a chunk is handed to the helpers only once it has arrived: a helper never waits
@@ -386,7 +464,8 @@ struct Download {
         hs.push_back(HostPool::get().submit(kStageThreads, [=](int t) { copy_item(stg, *pcs, nbytes, c * kStageThreads + t, false); }));
     }
     for (auto& h : hs) HostPool::wait(h);
-    if (e == hipSuccess && test_fail_finish()) e = hipErrorUnknown;
+    if (e == hipSuccess && test_fail_finish()) e = hipErrorUnknown;        // (test hook: fails AFTER the pieces were written)
+    landed = e == hipSuccess;
     return e;
   }
 };

@@ -30,7 +30,7 @@ def _colour_jobs(synth, n, seed0):
 
 def _want(oracle, j, flags, niter):
     kw = {n: j[n] for n in ("hsamp", "vsamp", "colorspace", "image_size") if n in j}
-    return oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+    return oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, threads=0, **kw)
 
 
 @pytest.mark.parametrize("nth", [1, 2, 3, 4, 5, 7])
@@ -161,16 +161,20 @@ def _raw_call(gpu, job, flags, niter, devices=None):
 
 
 @pytest.mark.parametrize("route", ["general", "sharded-set", "sharded-colour"])
+@pytest.mark.parametrize("size", [(1024, 768), (2048, 1536)], ids=["bands-under-1MiB", "staged-bands"])
 @pytest.mark.parametrize("nth", [1, 2])
-def test_reported_failure_leaves_the_image_untouched(gpu, oracle, synth, monkeypatch, route, nth):
+def test_reported_failure_leaves_the_image_untouched(gpu, oracle, synth, monkeypatch, route, size, nth):
     """results are scattered to caller memory piece by piece (per component, per band); a
     failure AFTER some pieces have been written must put the original blocks back -- the reference's
     applications ignore do_quantsmooth's return value and would write a half-smoothed, dequantised image
     with unchanged quant tables.  QS_HIP_TEST_FAIL_FINISH=N: the N-th scatter reports a HIP error after
-    writing its pieces."""
-    big = synth.synth_ycc(1024, 768, 2, 2, quality=50, seed=11)          # > 1 MiB per component: staged transfers
-    job = dict(coefs=big["coefs"], quants=big["quants"], hsamp=big["hsamp"], vsamp=big["vsamp"], colorspace=3, image_size=(1024, 768))
-    flags, devices = {"general": (7, None), "sharded-set": (1, [0, 0, 0]), "sharded-colour": (7, [0, 0, 0])}[route]
+    writing its pieces (where a restore copy exists: the pinned upload staging of transfers >= 1 MiB), or, where
+    none exists (small bands uploaded straight from caller memory), before anything is written: everything lands
+    in library-owned memory first."""
+    big = synth.synth_ycc(size[0], size[1], 2, 2, quality=50, seed=11)
+    job = dict(coefs=big["coefs"], quants=big["quants"], hsamp=big["hsamp"], vsamp=big["vsamp"], colorspace=3, image_size=size)
+    nb = 3 if size[0] == 1024 else 2
+    flags, devices = {"general": (7, None), "sharded-set": (1, [0] * nb), "sharded-colour": (7, [0] * nb)}[route]
     monkeypatch.setenv("QS_HIP_TEST_FAIL_FINISH", f"{nth}")
     try:
         rc, work, j = _raw_call(gpu, job, flags, 2, devices)
