@@ -473,6 +473,42 @@ __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >
 #ifndef QS_REFRESH_SKIP
 #define QS_REFRESH_SKIP 1
 #endif
+// the nine instructions of one term as a string, operands by name (for multi-term asm blocks)
+#define QS_TSTR(A, B, W) \
+          "v_sub_f32 %[d], %[" #A "], %[" #B "]\n\t" \
+          "v_sub_f32 %[t], %[r], |%[d]| clamp\n\t" \
+          "v_mul_f32 %[t], %[t], %[t]\n\t" \
+          "v_mul_f32 %[d], %[d], %[t]\n\t" \
+          "v_mul_f32 %[t], %[" #W "], %[t]\n\t" \
+          "v_mul_f32 %[d], %[d], %[t]\n\t" \
+          "v_add_f32 %[n], %[n], %[d]\n\t" \
+          "v_mul_f32 %[d], %[t], %[t]\n\t" \
+          "v_add_f32 %[e], %[e], %[d]\n\t"
+// one pixel row's seven horizontal differences (MODE 0), without x = 3 (MODE 1), without x = 1, 3, 5 (MODE 2)
+#define QS_HROW_TERMS_0 QS_TSTR(p0, p1, w0) QS_TSTR(p1, p2, w1) QS_TSTR(p2, p3, w2) QS_TSTR(p3, p4, w3) QS_TSTR(p4, p5, w4) QS_TSTR(p5, p6, w5) QS_TSTR(p6, p7, w6)
+#define QS_HROW_TERMS_1 QS_TSTR(p0, p1, w0) QS_TSTR(p1, p2, w1) QS_TSTR(p2, p3, w2) QS_TSTR(p4, p5, w4) QS_TSTR(p5, p6, w5) QS_TSTR(p6, p7, w6)
+#define QS_HROW_TERMS_2 QS_TSTR(p0, p1, w0) QS_TSTR(p2, p3, w2) QS_TSTR(p4, p5, w4) QS_TSTR(p6, p7, w6)
+#define QS_HROW_ASM(P, W, WO, MODE) { float d_, t_; \
+        asm volatile(QS_HROW_TERMS_##MODE \
+          : [n] "+v"(num), [e] "+v"(den), [d] "=&v"(d_), [t] "=&v"(t_) \
+          : [p0] "v"((P)[0]), [p1] "v"((P)[1]), [p2] "v"((P)[2]), [p3] "v"((P)[3]), [p4] "v"((P)[4]), [p5] "v"((P)[5]), \
+            [p6] "v"((P)[6]), [p7] "v"((P)[7]), [w0] "s"(W[(WO) + 0]), [w1] "s"(W[(WO) + 1]), [w2] "s"(W[(WO) + 2]), \
+            [w3] "s"(W[(WO) + 3]), [w4] "s"(W[(WO) + 4]), [w5] "s"(W[(WO) + 5]), [w6] "s"(W[(WO) + 6]), [r] "s"(Rs)); }
+// one row of eight vertical differences: row P against row Q (the next pixel row)
+#define QS_VROW_ASM(P, Q, W, WO) { float d_, t_; \
+        asm volatile(QS_TSTR(p0, q0, w0) QS_TSTR(p1, q1, w1) QS_TSTR(p2, q2, w2) QS_TSTR(p3, q3, w3) \
+                     QS_TSTR(p4, q4, w4) QS_TSTR(p5, q5, w5) QS_TSTR(p6, q6, w6) QS_TSTR(p7, q7, w7) \
+          : [n] "+v"(num), [e] "+v"(den), [d] "=&v"(d_), [t] "=&v"(t_) \
+          : [p0] "v"((P)[0]), [p1] "v"((P)[1]), [p2] "v"((P)[2]), [p3] "v"((P)[3]), [p4] "v"((P)[4]), [p5] "v"((P)[5]), \
+            [p6] "v"((P)[6]), [p7] "v"((P)[7]), [q0] "v"((Q)[0]), [q1] "v"((Q)[1]), [q2] "v"((Q)[2]), [q3] "v"((Q)[3]), \
+            [q4] "v"((Q)[4]), [q5] "v"((Q)[5]), [q6] "v"((Q)[6]), [q7] "v"((Q)[7]), \
+            [w0] "s"(W[(WO) + 0]), [w1] "s"(W[(WO) + 1]), [w2] "s"(W[(WO) + 2]), [w3] "s"(W[(WO) + 3]), \
+            [w4] "s"(W[(WO) + 4]), [w5] "s"(W[(WO) + 5]), [w6] "s"(W[(WO) + 6]), [w7] "s"(W[(WO) + 7]), [r] "s"(Rs)); }
+// QS_SECTION_SPEC=1: the zero-weight skip is decided once per horizontal / vertical section (three
+// specialised copies of the section) instead of by a scalar compare-and-branch in front of 48 terms
+#ifndef QS_SECTION_SPEC
+#define QS_SECTION_SPEC 0
+#endif
 #ifndef QS_TAIL_PRIO
 #define QS_TAIL_PRIO 1
 #endif
@@ -503,6 +539,21 @@ __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >
 #else
 #define QS_TERM_OPT(COND, A, B, W) QS_TERM(A, B, W)
 #endif
+// the same nine instructions as one opaque block (QS_SECTION_SPEC: the three specialised copies of a section must
+// not share subexpressions, or hipcc hoists ~100 pixel differences above the branch and spills them)
+#define QS_TERM_ASM(A, B, W) { float d_, t_; \
+        asm volatile( \
+          "v_sub_f32 %[d], %[a], %[b]\n\t" \
+          "v_sub_f32 %[t], %[r], |%[d]| clamp\n\t" \
+          "v_mul_f32 %[t], %[t], %[t]\n\t" \
+          "v_mul_f32 %[d], %[d], %[t]\n\t" \
+          "v_mul_f32 %[t], %[w], %[t]\n\t" \
+          "v_mul_f32 %[d], %[d], %[t]\n\t" \
+          "v_add_f32 %[n], %[n], %[d]\n\t" \
+          "v_mul_f32 %[d], %[t], %[t]\n\t" \
+          "v_add_f32 %[e], %[e], %[d]" \
+          : [n] "+v"(num), [e] "+v"(den), [d] "=&v"(d_), [t] "=&v"(t_) \
+          : [a] "v"(A), [b] "v"(B), [w] "s"(W), [r] "s"(Rs)); }
 
 // Two instantiations of the kernel body (qs_smooth_kernel.inc):
 //   qs_smooth_plane_kernel      the default: scalar weights streamed through an

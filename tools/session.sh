@@ -12,7 +12,8 @@
 #   cold            tools/cold_phases (fresh-process phase times) for 1080p and 8192^2, three runs each
 #   cli[:size]      tools/bench_cli.py (drop-in CLI against the reference CLIs on libjpeg-encoded files)
 #   sizes:<args>    tools/bench_sizes.py <args>
-#   py:<name>:<script>:<args...>  any tools/*.py script
+#   py:<name>:<script>:<args...>  any tools/*.py script;  pyenv:<name>:<VAR=value>:<script>:<args...> with one environment variable
+#   exe:<name>:<path>       a prebuilt measurement binary
 set -u
 export TMPDIR=/tmp
 R=$PWD
@@ -53,6 +54,12 @@ for step in "$@"; do
     py)
       name=${rest%%:*}; r2=${rest#*:}; script=${r2%%:*}; args=${r2#*:}; [ "$args" = "$r2" ] && args=""
       timeout 1200 python tools/$script ${args//,/ } > $O/$name.txt 2>&1; tail -30 $O/$name.txt ;;
+    pyenv)    # pyenv:<name>:<VAR=value>:<script>:<args...>
+      name=${rest%%:*}; r2=${rest#*:}; var=${r2%%:*}; r3=${r2#*:}; script=${r3%%:*}; args=${r3#*:}; [ "$args" = "$r3" ] && args=""
+      env "$var" timeout 1200 python tools/$script ${args//,/ } > $O/$name.txt 2>&1; tail -30 $O/$name.txt ;;
+    exe)      # exe:<name>:<path>  -- a prebuilt measurement binary (build/ubench_clock ...)
+      name=${rest%%:*}; path=${rest#*:}
+      timeout 600 $path > $O/$name.txt 2>&1; tail -40 $O/$name.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done
