@@ -56,6 +56,18 @@ ALGO_BYTES_PER_BLOCK_ITER = 256
 RESIDENT_BUDGET = 64 << 30     # HBM the resident input planes of all steps may take
 
 
+def _sustained(achieved_tf):
+    """the same fraction against what the chip SUSTAINS for a pure stream of this kernel's term instructions
+    (profiles/valu_sustained.json, measured with tools/ubench_clock.hip): the shader clock under a full VALU load
+    is ~2.2 GHz, not the 2.4 GHz the nominal peak assumes, and a SIMD issues one wave-instruction per 2.11 cycles"""
+    try:
+        j = json.loads((ROOT / "profiles" / "valu_sustained.json").read_text())
+        peak = float(j["lane_instr_per_s"]) / 1e12
+        return {"sustained_peak": peak, "frac_of_sustained": achieved_tf / peak, "sustained_source": j["_source"]}
+    except Exception:
+        return {}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -312,7 +324,8 @@ def main():
             "roofline_valu": {"bound": "fp32-valu (separate mul/add, FMA forbidden by bit-exactness)",
                               "achieved": achieved_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved_tf / VALU_PEAK_TFLOPS,
-                              "flop_per_block_iter": FLOP_PER_BLOCK_ITER[flags & 1]},
+                              "flop_per_block_iter": FLOP_PER_BLOCK_ITER[flags & 1],
+                              **_sustained(achieved_tf)},
         }
         for k in ("single_plane_ms", "value_batch1", "planes_identical", "smooth_input", "product_route", "verify_against"):
             if res.get(k) is not None:

@@ -341,7 +341,13 @@ inline hipError_t upload_pieces(void* dst, const std::vector<Piece>& pieces, siz
   // up at ~44 GB/s here, pinning 128 MiB costs 23 ms (tools/cold_phases) -- unless they come in many pieces
   if ((bytes < kStageMin && pieces.size() <= 4) || !stage.alloc(bytes, /*optional=*/pieces.size() <= 16)) {
     for (const Piece& pc : pieces) {
-      hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + pc.off, pc.host, pc.len, hipMemcpyHostToDevice, s);
+      // A large pageable piece goes through the BLOCKING copy: measured on the MI355X box (tools/cold_phases,
+      // profiles/r03c) hipMemcpy moves 128 MiB of pageable memory in 3 ms (44 GB/s: the runtime pins the user pages on
+      // the fly), hipMemcpyAsync on a stream takes the bounce-buffer path at ~6 GB/s.  The copy is complete when
+      // the call returns, so whatever is queued on `s` afterwards sees the data.
+      hipError_t e = pc.len >= kStageMin
+          ? hipMemcpy(static_cast<char*>(dst) + pc.off, pc.host, pc.len, hipMemcpyHostToDevice)
+          : hipMemcpyAsync(static_cast<char*>(dst) + pc.off, pc.host, pc.len, hipMemcpyHostToDevice, s);
       if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -423,8 +429,8 @@ struct Download {
     } else if (bytes) {
       tmp = malloc(bytes);
       if (!tmp) return hipErrorOutOfMemory;
-      e = hipMemcpyAsync(tmp, src, bytes, hipMemcpyDeviceToHost, s);
-      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      e = hipStreamSynchronize(s);                  // then the blocking copy: the fast pageable path (see upload_pieces)
+      if (e == hipSuccess) e = hipMemcpy(tmp, src, bytes, hipMemcpyDeviceToHost);
     } else {
       e = hipStreamSynchronize(s);
     }

@@ -30,7 +30,9 @@ def _colour_jobs(synth, n, seed0):
 
 def _want(oracle, j, flags, niter):
     kw = {n: j[n] for n in ("hsamp", "vsamp", "colorspace", "image_size") if n in j}
-    return oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, threads=0, **kw)
+    # (threads: the box reports 256 logical CPUs on a 16-core quota; an OpenMP team of 256 is slower than one thread here)
+    nblk = sum(int(c.shape[0] * c.shape[1]) for c in j["coefs"])
+    return oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, threads=8 if nblk > 30000 else 1, **kw)
 
 
 @pytest.mark.parametrize("nth", [1, 2, 3, 4, 5, 7])
@@ -200,8 +202,8 @@ sys.path.insert(0, "tests")
 import jpegqs_pkg
 from oracle.oracle import Oracle
 from helpers import assert_same_result
-from jpeg_quantsmooth_amd.hipqs import PROGRESS_FN
 pkg = jpegqs_pkg.load(); hip = pkg.HipQS(); O = Oracle()
+from jpeg_quantsmooth_amd.hipqs import PROGRESS_FN
 coef, quant = pkg.synth.synth_gray(64, 512, 50, seed=3)          # 8 x 64 blocks -> 13 bands of <= 5 rows + halo
 for nth in (2, 3, 13):
     j, work = hip._make_job([coef], [quant])

@@ -4,7 +4,7 @@
 # Writes small CSV summaries under gpurun_out/prof_<tag>/ (copy to profiles/ to commit).
 set -u
 TAG=${1:-r01}; shift || true
-ARGS="${@:---steps 2 --warmup 1 --no-cpu-baseline --no-verify}"
+ARGS="${@:---steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-extras}"
 export TMPDIR=/tmp
 REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
