@@ -516,6 +516,7 @@ int qsj::do_quantsmooth_impl(qs_hip_job* job, int flags, int niter, int progprec
 // The C ABI never lets a C++ exception (std::bad_alloc from the host-side containers) escape.
 extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int progprec,
                                      qs_hip_progress_fn progress, void* userdata) {
+  struct Kick { ~Kick() { PinnedBuf::kick_fills(); } } kick;   // staging blocks this call missed are pinned afterwards
   try {
     return do_quantsmooth_impl(job, flags, niter, progprec, progress, userdata);
   } catch (const std::bad_alloc&) {
@@ -535,6 +536,7 @@ extern "C" int qs_hip_do_quantsmooth_rows(qs_hip_job* job, int16_t* const* const
       for (int y = 0; y < job->hblk[ci]; ++y)
         if (!rows[ci][y]) return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth_rows: component %d row %d is null", ci, y);
     }
+    struct Kick { ~Kick() { PinnedBuf::kick_fills(); } } kick;
     RowScope scope(rows);
     return do_quantsmooth_impl(job, flags, niter, progprec, progress, userdata);
   } catch (const std::bad_alloc&) {
@@ -547,6 +549,7 @@ extern "C" int qs_hip_do_quantsmooth_rows(qs_hip_job* job, int16_t* const* const
 extern "C" int qs_hip_do_quantsmooth_sharded(qs_hip_job* job, int flags, int niter, const int* devices, int ndev) {
   try {
     if (!devices || ndev < 1) return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth_sharded: empty device list");
+    struct Kick { ~Kick() { PinnedBuf::kick_fills(); } } kick;
     const int todo = prepare_job(job, flags, &niter);
     if (todo <= 0) return todo;
     warm_wait();

@@ -177,24 +177,42 @@ struct PinnedBuf {
     static const int m = [] { const char* v = getenv("QS_HIP_UPLOAD_STAGE"); return !v ? 2 : atoi(v) ? 1 : 0; }();
     return m;
   }
+  // Blocks wanted for next time.  They are pinned by ONE background thread that starts when the job that missed
+  // them has finished (kick_fills, called by the entry points on their way out): pinning takes the process's
+  // mmap lock, and done during the job it slowed the job's own pageable copies down to a third.
+  static std::vector<std::pair<size_t, int>>& pending() { static std::vector<std::pair<size_t, int>> v; return v; }
   static void fill_later(size_t want) {
-    static std::atomic<int> busy{0};
-    if (busy.fetch_add(1) >= 2) { busy.fetch_sub(1); return; }          // at most two fills at a time
-    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (pending().size() < 16) pending().push_back({want, current_device()});
+  }
+  static void kick_fills() {
+    static std::atomic<bool> busy{false};
+    {
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      if (pending().empty()) return;
+    }
+    if (busy.exchange(true)) return;                                     // the running thread takes the new entries too
     try {
-      std::thread([want, dev] {
-        (void)hipSetDevice(dev);
-        void* q = nullptr;
-        if (hipHostMalloc(&q, want, hipHostMallocPortable) == hipSuccess) {
-          std::lock_guard<std::mutex> lk(g_cache_mu);
-          size_t held = 0;
-          for (auto& c : pool()) held += c.n;
-          if (held + want <= ((size_t)2 << 30)) { pool().push_back({q, want, -1}); q = nullptr; }
-        } else (void)hipGetLastError();
-        if (q) (void)hipHostFree(q);
-        busy.fetch_sub(1);
+      std::thread([] {
+        for (;;) {
+          std::pair<size_t, int> job;
+          {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            if (pending().empty()) { busy = false; return; }
+            job = pending().back(); pending().pop_back();
+          }
+          (void)hipSetDevice(job.second);
+          void* q = nullptr;
+          if (hipHostMalloc(&q, job.first, hipHostMallocPortable) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            size_t held = 0;
+            for (auto& c : pool()) held += c.n;
+            if (held + job.first <= ((size_t)2 << 30)) { pool().push_back({q, job.first, -1}); q = nullptr; }
+          } else (void)hipGetLastError();
+          if (q) (void)hipHostFree(q);
+        }
       }).detach();
-    } catch (...) { busy.fetch_sub(1); }
+    } catch (...) { busy = false; }
   }
   void release() {
     if (!p) return;

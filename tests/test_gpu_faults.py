@@ -192,10 +192,13 @@ def test_reported_failure_leaves_the_image_untouched(gpu, oracle, synth, monkeyp
     assert_same_result(again, _want(oracle, job, flags, 2), f"{route}: the call after the injected failure")
 
 
-def test_reported_failure_leaves_a_banded_image_untouched():
-    """the same for the fused route with the plane cut into pipelined bands (run_fused): bands are written back
-    while later bands are still in flight; the failing scatter is the 2nd / 3rd / last band's"""
-    from test_gpu_parity import _BAND_ENV, _run_py
+@pytest.mark.parametrize("width,band_blocks,kind", [(64, 128, "small bands: no restore copy, everything lands first"),
+                                                     (2048, 8192, "1 MiB bands: written early, restored from the upload staging")])
+def test_reported_failure_leaves_a_banded_image_untouched(width, band_blocks, kind):
+    """the same for the fused route with the plane cut into pipelined bands (run_fused): with a pinned upload staging
+    copy the bands are written back while later bands are still in flight and a failure restores them; without one
+    (bands under 1 MiB) they are held back until every band has landed.  The failing scatter is the 2nd / 3rd / last."""
+    from test_gpu_parity import _run_py
     code = r'''
 import sys, ctypes as C, os, numpy as np
 sys.path.insert(0, "tests")
@@ -204,16 +207,20 @@ from oracle.oracle import Oracle
 from helpers import assert_same_result
 pkg = jpegqs_pkg.load(); hip = pkg.HipQS(); O = Oracle()
 from jpeg_quantsmooth_amd.hipqs import PROGRESS_FN
-coef, quant = pkg.synth.synth_gray(64, 512, 50, seed=3)          # 8 x 64 blocks -> 13 bands of <= 5 rows + halo
-for nth in (2, 3, 13):
+width = int(sys.argv[1])
+coef, quant = pkg.synth.synth_gray(width, 1024, 50, seed=3)       # 128 block rows -> 8 / 4 bands of 16 / 32 rows + halo
+want = O.do_quantsmooth([coef], [quant], 1, 1, threads=8)
+for nth in (2, 3, int(sys.argv[2])):
     j, work = hip._make_job([coef], [quant])
     os.environ["QS_HIP_TEST_FAIL_FINISH"] = str(nth)
-    rc = hip.lib.qs_hip_do_quantsmooth(C.byref(j), 1, 2, 0, C.cast(None, PROGRESS_FN), None)
+    rc = hip.lib.qs_hip_do_quantsmooth(C.byref(j), 1, 1, 0, C.cast(None, PROGRESS_FN), None)
     del os.environ["QS_HIP_TEST_FAIL_FINISH"]
     assert rc < 0, (nth, rc)
     assert np.array_equal(work[0], coef), f"nth={nth}: rows left modified after a reported failure"
     assert list(j.quant[0][:]) == [int(v) for v in quant]
-    assert_same_result(hip.do_quantsmooth([coef], [quant], 1, 2), O.do_quantsmooth([coef], [quant], 1, 2), f"after nth={nth}")
+    assert_same_result(hip.do_quantsmooth([coef], [quant], 1, 1), want, f"after nth={nth}")
 print("ok")
 '''
-    assert "ok" in _run_py(code, dict(_BAND_ENV, QS_HIP_TEST_HOOKS="1"))
+    nbands = (width // 8) * 128 // band_blocks
+    env = {"QS_HIP_SPLIT_BLOCKS": "60", "QS_HIP_BAND_BLOCKS": str(band_blocks), "QS_HIP_TEST_HOOKS": "1"}
+    assert "ok" in _run_py("import sys; sys.argv = ['x', '%d', '%d']\n" % (width, nbands) + code, env), kind
