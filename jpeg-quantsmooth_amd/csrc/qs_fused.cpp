@@ -99,16 +99,18 @@ static void partition(const qs_hip_job* const* jobs, const std::vector<int>& whi
 
 }  // namespace
 
-// the pinned staging sizes a plane-set run of this one job will ask for (upload and download alike): one per group
-void qsj::fused_stage_sizes(const qs_hip_job* job, int niter, std::vector<size_t>& out) {
+// what a plane-set run of this one job will ask for, one entry per group: the coefficient bytes (= the size of its
+// pinned upload staging, of its pinned download landing buffer and of its device arena) and the bytes of its pixel planes
+void qsj::fused_stage_sizes(const qs_hip_job* job, int niter, std::vector<size_t>& coef_bytes, std::vector<size_t>& px_bytes) {
   std::list<FGroup> groups;
   std::vector<char> split(1, 0);
   const qs_hip_job* one[1] = { job };
   partition(one, std::vector<int>{0}, niter, groups, split);
   for (const FGroup& G : groups) {
-    size_t n = 0;
-    for (const FPlane& P : G.planes) n += P.cbytes;
-    out.push_back(n);
+    size_t n = 0, px = 0;
+    for (const FPlane& P : G.planes) { n += P.cbytes; px += (qs_hip_plane_bytes(P.wb, P.hb) + 255) & ~(size_t)255; }
+    coef_bytes.push_back(n);
+    px_bytes.push_back(px);
   }
 }
 
@@ -131,6 +133,7 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
   const int diag = (flags & QS_DIAGONALS) != 0;
   size_t gi = 0;
   auto enqueue = [&](FGroup& G) -> int {
+    const double t_g0 = wall_ms();
     G.s = lease.p->get((int)(gi++ % 3));
     const int np = (int)G.planes.size();
     size_t coef_bytes = 0, px_bytes = 0;
@@ -155,7 +158,11 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
     for (const FPlane& P : G.planes)
       host_pieces(jobs[P.job], P.ci, P.src_row0, P.hb, P.coef_off, pieces);
     G.coef_bytes = coef_bytes;
+    const double t_up0 = wall_ms();
     HIP_TRY(upload_pieces(G.coef.p, pieces, coef_bytes, G.s, G.stage));
+    if (trace_on())
+      fprintf(stderr, "qs_hip trace: fused  group %zu: alloc+consts %.2f ms, upload of %.1f MiB in %zu piece(s) %.2f ms (%s)\n",
+              gi, t_up0 - t_g0, coef_bytes / 1048576.0, pieces.size(), wall_ms() - t_up0, G.stage.p ? "staged" : "direct");
     HIP_TRY(hipMemsetAsync(G.status.p, 0, (size_t)np * sizeof(int32_t), G.s));
 
     QsPlaneSet set;

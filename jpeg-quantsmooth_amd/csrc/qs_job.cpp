@@ -393,18 +393,28 @@ void warm_runtime() {
   if (trace_on()) fprintf(stderr, "qs_hip trace: prewarm  context+queue %.2f ms  first copy+kernel+helpers %.2f ms\n", t1 - t0, wall_ms() - t1);
 }
 
-void warm_pools(std::vector<size_t> sizes) {
+void warm_pools(std::vector<size_t> pinned, std::vector<size_t> device) {
   const double t0 = wall_ms();
+  {
+    std::vector<std::unique_ptr<DevBuf>> hold;               // cold hipMalloc of a band's arenas costs 3-9 ms per group
+    for (size_t n : device) {
+      std::unique_ptr<DevBuf> b(new DevBuf);
+      if (b->alloc(n) != hipSuccess) { (void)hipGetLastError(); break; }
+      hold.push_back(std::move(b));
+    }
+  }
+  const double t1 = wall_ms();
   std::vector<std::unique_ptr<PinnedBuf>> hold;              // all at once: distinct blocks; released to the pool together
   size_t total = 0;
-  for (size_t n : sizes) {
+  for (size_t n : pinned) {
     if (n < kStageMin || total + round_size(n) > ((size_t)2 << 30)) continue;
     std::unique_ptr<PinnedBuf> b(new PinnedBuf);
     if (!b->alloc(n)) break;
     total += b->n;
     hold.push_back(std::move(b));
   }
-  if (trace_on()) fprintf(stderr, "qs_hip trace: prewarm  %zu pinned block(s), %.0f MiB: %.2f ms\n", hold.size(), total / 1048576.0, wall_ms() - t0);
+  if (trace_on()) fprintf(stderr, "qs_hip trace: prewarm  %zu device buffer(s) %.2f ms, %zu pinned block(s), %.0f MiB: %.2f ms\n",
+                          device.size(), t1 - t0, hold.size(), total / 1048576.0, wall_ms() - t1);
 }
 }  // namespace
 
@@ -415,7 +425,7 @@ void qsj::warm_wait() {
 
 extern "C" int qs_hip_prewarm(const qs_hip_job* geometry, int flags, int niter) {
   try {
-    std::vector<size_t> sizes;
+    std::vector<size_t> sizes, device;
     if (geometry && geometry->ncomp >= 1 && geometry->ncomp <= QS_HIP_MAXC) {
       qs_hip_job g = *geometry;
       int nit = niter;
@@ -423,20 +433,26 @@ extern "C" int qs_hip_prewarm(const qs_hip_job* geometry, int flags, int niter) 
       for (int ci = 0; ci < g.ncomp; ++ci) ok = ok && g.wblk[ci] > 0 && g.hblk[ci] > 0 && (long long)g.wblk[ci] * g.hblk[ci] <= (1ll << 27);
       if (ok) {
         nit = nit < 0 ? 0 : nit > 100 ? 100 : nit;
-        std::vector<size_t> one;
-        if (job_fusable(&g, flags)) fused_stage_sizes(&g, nit, one);
-        else for (int ci = 0; ci < g.ncomp; ++ci) one.push_back((size_t)g.wblk[ci] * g.hblk[ci] * 128);
-        for (size_t n : one) sizes.push_back(n);     // the download landing buffers (a first call uploads straight from the caller's memory)
+        std::vector<size_t> one, px;
+        if (job_fusable(&g, flags)) fused_stage_sizes(&g, nit, one, px);
+        else for (int ci = 0; ci < g.ncomp; ++ci) {
+          one.push_back((size_t)g.wblk[ci] * g.hblk[ci] * 128);
+          px.push_back(qs_hip_plane_bytes(g.wblk[ci], g.hblk[ci]));
+        }
+        for (size_t k = 0; k < one.size(); ++k) {
+          sizes.push_back(one[k]); sizes.push_back(one[k]);   // upload staging + download landing buffer
+          device.push_back(one[k]); device.push_back(px[k]);  // coefficient arena + pixel planes
+        }
         if ((flags & QS_UPSAMPLE_UV) && job_needs_lowres(&g, flags) && !(g.hsamp[0] == 1 && g.vsamp[0] == 1))
           for (int k = 0; k < 2; ++k) sizes.push_back((size_t)g.wblk[0] * g.hblk[0] * 128);   // the replacement arrays
       }
     }
     { std::lock_guard<std::mutex> lk(g_warm_mu); ++g_warm_running; }
-    std::thread([sizes]() {
+    std::thread([sizes, device]() {
       try {
         std::call_once(g_warm_runtime_once, warm_runtime);
         int n = 0;
-        if (!sizes.empty() && hipGetDeviceCount(&n) == hipSuccess && n > 0) warm_pools(sizes);
+        if (!sizes.empty() && hipGetDeviceCount(&n) == hipSuccess && n > 0) warm_pools(sizes, device);
       } catch (...) {}
       { std::lock_guard<std::mutex> lk(g_warm_mu); --g_warm_running; }
       g_warm_cv.notify_all();

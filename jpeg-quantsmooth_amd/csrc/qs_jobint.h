@@ -47,8 +47,8 @@ int run_job(qs_hip_job* job, int flags, int niter, int progprec,
 // qs_hip_do_quantsmooth would have returned for that job.  Returns 0, or < 0 when the route failed (a job whose
 // rows had already been written is then either complete, results[ji] == 0, or restored to its input).
 int run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int flags, int niter, int* results);
-// (prewarm) the pinned staging sizes run_fused will ask for, one per group, for this one job
-void fused_stage_sizes(const qs_hip_job* job, int niter, std::vector<size_t>& out);
+// (prewarm) the buffer sizes run_fused will ask for, one entry per group, for this one job
+void fused_stage_sizes(const qs_hip_job* job, int niter, std::vector<size_t>& coef_bytes, std::vector<size_t>& px_bytes);
 // validation and the reference's early-outs (1: work to do, 0: finished with result 0, < 0: bad job), and
 // the single-job dispatcher behind qs_hip_do_quantsmooth (qs_job.cpp)
 int prepare_job(qs_hip_job* job, int flags, int* niter);

@@ -91,6 +91,21 @@ int main(int argc, char** argv) {
     const int ms = atoi(pw);
     PHASE("application busy elsewhere (simulated decode)", { const double t = now_ms(); while (now_ms() - t < ms) {} });
   }
+  if (!skip_runtime && getenv("COLD_COPY_PROBE")) {
+    // how fast do pageable pieces of the size of one band (36 MiB) go up, blocking vs on a stream?
+    void* d = nullptr; (void)hipMalloc(&d, (size_t)40 << 20);
+    hipStream_t st; (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    const size_t n = (size_t)36 << 20;
+    char* src = reinterpret_cast<char*>(coef[0].data());
+    if (coef[0].size() * 2 >= 3 * n) {
+      PHASE("hipMemcpy 36 MiB pageable (job array, piece 1)", (void)hipMemcpy(d, src, n, hipMemcpyHostToDevice));
+      PHASE("hipMemcpy 36 MiB pageable (job array, piece 2)", (void)hipMemcpy(d, src + n, n, hipMemcpyHostToDevice));
+      PHASE("hipMemcpy 36 MiB pageable (piece 1 again)", (void)hipMemcpy(d, src, n, hipMemcpyHostToDevice));
+      PHASE("hipMemcpyAsync + sync 36 MiB pageable (piece 3)", { (void)hipMemcpyAsync(d, src + 2 * n, n, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st); });
+      PHASE("hipMemcpyAsync + sync 36 MiB pageable (piece 3 again)", { (void)hipMemcpyAsync(d, src + 2 * n, n, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st); });
+    }
+    (void)hipStreamDestroy(st); (void)hipFree(d);
+  }
   if (!skip_runtime) {
     // first launch of a kernel of the product library: code-object load
     void* d = nullptr; (void)hipMalloc(&d, 1 << 20); (void)hipMemset(d, 0, 1 << 20);

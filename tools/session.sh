@@ -41,7 +41,7 @@ for step in "$@"; do
       timeout 900 python tools/bench_variants.py ${rest:-8192} > $O/variants_${rest:-8192}.txt 2>&1; cat $O/variants_${rest:-8192}.txt ;;
     cold)
       for i in 1 2 3; do ./tools/cold_phases 1920 1080 3; done > $O/cold_1080p.txt 2>&1
-      for i in 1 2 3; do ./tools/cold_phases 8192 8192 1; done > $O/cold_8192.txt 2>&1
+      for i in 1 2 3; do COLD_COPY_PROBE=1 QS_HIP_TRACE=1 ./tools/cold_phases 8192 8192 1; done > $O/cold_8192.txt 2>&1
       for i in 1 2; do COLD_SKIP_RUNTIME=1 QS_HIP_TRACE=1 ./tools/cold_phases 1920 1080 3; done > $O/cold_1080p_libfirst.txt 2>&1
       for i in 1 2; do COLD_SKIP_RUNTIME=1 QS_HIP_TRACE=1 ./tools/cold_phases 8192 8192 1; done > $O/cold_8192_libfirst.txt 2>&1
       for ms in 0 20 150; do COLD_SKIP_RUNTIME=1 COLD_PREWARM=$ms QS_HIP_TRACE=1 ./tools/cold_phases 1920 1080 3; done > $O/cold_1080p_prewarm.txt 2>&1
