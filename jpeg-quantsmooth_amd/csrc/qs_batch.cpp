@@ -431,7 +431,7 @@ static int do_quantsmooth_batch_impl(qs_hip_job* const* jobs, int njobs, int fla
 }
 
 extern "C" int qs_hip_do_quantsmooth_batch(qs_hip_job* const* jobs, int njobs, int flags, int niter, int* results) {
-  struct Kick { ~Kick() { PinnedBuf::kick_fills(); } } kick;
+  struct Kick { ~Kick() { kick_background(); } } kick;
   try {
     return do_quantsmooth_batch_impl(jobs, njobs, flags, niter, results);
   } catch (const std::bad_alloc&) {

@@ -134,7 +134,7 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
   size_t gi = 0;
   auto enqueue = [&](FGroup& G) -> int {
     const double t_g0 = wall_ms();
-    G.s = lease.p->get((int)(gi++ % 3));
+    G.s = lease.p->get_ready((int)(gi++ % 3));
     const int np = (int)G.planes.size();
     size_t coef_bytes = 0, px_bytes = 0;
     std::vector<const uint16_t*> qtabs;
@@ -146,14 +146,20 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
         if (!memcmp(qtabs[k], q, 64 * sizeof(uint16_t))) P.cst = (int)k;
       if (P.cst < 0) { P.cst = (int)qtabs.size(); qtabs.push_back(q); }
     }
+    const double t_a0 = wall_ms();
     HIP_TRY(G.coef.alloc(coef_bytes));
     HIP_TRY(G.px.alloc(px_bytes));
     HIP_TRY(G.cst.alloc(qtabs.size() * sizeof(QsConsts)));
     HIP_TRY(G.status.alloc((size_t)np * sizeof(int32_t)));
+    const double t_a1 = wall_ms();
     G.hc.resize(qtabs.size());
     for (size_t k = 0; k < qtabs.size(); ++k)
       if (int r = qs_hip_consts_build(&G.hc[k], qtabs[k], flags)) return r;
+    const double t_a2 = wall_ms();
     HIP_TRY(hipMemcpyAsync(G.cst.p, G.hc.data(), qtabs.size() * sizeof(QsConsts), hipMemcpyHostToDevice, G.s));
+    if (trace_on())
+      fprintf(stderr, "qs_hip trace: fused  group %zu: stream %.2f ms, device buffers %.2f ms, consts build %.2f ms, consts copy %.2f ms\n",
+              gi, t_a0 - t_g0, t_a1 - t_a0, t_a2 - t_a1, wall_ms() - t_a2);
     std::vector<Piece> pieces;
     for (const FPlane& P : G.planes)
       host_pieces(jobs[P.job], P.ci, P.src_row0, P.hb, P.coef_off, pieces);

@@ -127,7 +127,7 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
 
     // stream: luma (and anything coupled to it) on stream 0; independent
     // components round-robin
-    hipStream_t s = st.get(eager ? ci % nstreams : 0);
+    hipStream_t s = st.get_ready(eager ? ci % nstreams : 0);   // (extra streams only once they exist: see Streams::get_ready)
     C.stream = s; C.processed = true;
     HIP_TRY(C.coef.alloc(cbytes));
     HIP_TRY(C.cst.alloc(sizeof(QsConsts)));
@@ -379,7 +379,7 @@ void warm_runtime() {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return; }
   const double t0 = wall_ms();
-  { StreamLease lease; (void)lease; }                        // device context + first queue, parked in the pool
+  { StreamLease lease; if (lease.p) lease.p->warm_all(); }   // device context + the three queues, each with its first copy done; parked in the pool
   const double t1 = wall_ms();
   DevBuf d; PinnedBuf h;
   if (d.alloc(1 << 20) == hipSuccess && h.alloc(1 << 20)) {
@@ -532,7 +532,7 @@ int qsj::do_quantsmooth_impl(qs_hip_job* job, int flags, int niter, int progprec
 // The C ABI never lets a C++ exception (std::bad_alloc from the host-side containers) escape.
 extern "C" int qs_hip_do_quantsmooth(qs_hip_job* job, int flags, int niter, int progprec,
                                      qs_hip_progress_fn progress, void* userdata) {
-  struct Kick { ~Kick() { PinnedBuf::kick_fills(); } } kick;   // staging blocks this call missed are pinned afterwards
+  struct Kick { ~Kick() { kick_background(); } } kick;   // staging blocks this call missed are pinned afterwards
   try {
     return do_quantsmooth_impl(job, flags, niter, progprec, progress, userdata);
   } catch (const std::bad_alloc&) {
@@ -552,7 +552,7 @@ extern "C" int qs_hip_do_quantsmooth_rows(qs_hip_job* job, int16_t* const* const
       for (int y = 0; y < job->hblk[ci]; ++y)
         if (!rows[ci][y]) return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth_rows: component %d row %d is null", ci, y);
     }
-    struct Kick { ~Kick() { PinnedBuf::kick_fills(); } } kick;
+    struct Kick { ~Kick() { kick_background(); } } kick;
     RowScope scope(rows);
     return do_quantsmooth_impl(job, flags, niter, progprec, progress, userdata);
   } catch (const std::bad_alloc&) {
@@ -565,7 +565,7 @@ extern "C" int qs_hip_do_quantsmooth_rows(qs_hip_job* job, int16_t* const* const
 extern "C" int qs_hip_do_quantsmooth_sharded(qs_hip_job* job, int flags, int niter, const int* devices, int ndev) {
   try {
     if (!devices || ndev < 1) return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth_sharded: empty device list");
-    struct Kick { ~Kick() { PinnedBuf::kick_fills(); } } kick;
+    struct Kick { ~Kick() { kick_background(); } } kick;
     const int todo = prepare_job(job, flags, &niter);
     if (todo <= 0) return todo;
     warm_wait();

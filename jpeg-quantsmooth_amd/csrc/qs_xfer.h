@@ -185,34 +185,26 @@ struct PinnedBuf {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     if (pending().size() < 16) pending().push_back({want, current_device()});
   }
-  static void kick_fills() {
-    static std::atomic<bool> busy{false};
-    {
-      std::lock_guard<std::mutex> lk(g_cache_mu);
-      if (pending().empty()) return;
+  static bool fills_pending() { std::lock_guard<std::mutex> lk(g_cache_mu); return !pending().empty(); }
+  // pin everything on the list (on the calling thread: the background thread of kick_background)
+  static void run_pending_fills() {
+    for (;;) {
+      std::pair<size_t, int> job;
+      {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (pending().empty()) return;
+        job = pending().back(); pending().pop_back();
+      }
+      (void)hipSetDevice(job.second);
+      void* q = nullptr;
+      if (hipHostMalloc(&q, job.first, hipHostMallocPortable) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        size_t held = 0;
+        for (auto& c : pool()) held += c.n;
+        if (held + job.first <= ((size_t)2 << 30)) { pool().push_back({q, job.first, -1}); q = nullptr; }
+      } else (void)hipGetLastError();
+      if (q) (void)hipHostFree(q);
     }
-    if (busy.exchange(true)) return;                                     // the running thread takes the new entries too
-    try {
-      std::thread([] {
-        for (;;) {
-          std::pair<size_t, int> job;
-          {
-            std::lock_guard<std::mutex> lk(g_cache_mu);
-            if (pending().empty()) { busy = false; return; }
-            job = pending().back(); pending().pop_back();
-          }
-          (void)hipSetDevice(job.second);
-          void* q = nullptr;
-          if (hipHostMalloc(&q, job.first, hipHostMallocPortable) == hipSuccess) {
-            std::lock_guard<std::mutex> lk(g_cache_mu);
-            size_t held = 0;
-            for (auto& c : pool()) held += c.n;
-            if (held + job.first <= ((size_t)2 << 30)) { pool().push_back({q, job.first, -1}); q = nullptr; }
-          } else (void)hipGetLastError();
-          if (q) (void)hipHostFree(q);
-        }
-      }).detach();
-    } catch (...) { busy = false; }
   }
   void release() {
     if (!p) return;
@@ -512,6 +504,28 @@ struct Streams {
     }
     return s[i];
   }
+  // s[i] if it exists already, else s[0]: a job that would merely like to overlap its groups does not stop for 9 ms
+  // to create a queue (and 9 more for the first copy on it); the missing ones are created after the call (warm_all
+  // from the background thread of PinnedBuf::kick_fills, or by qs_hip_prewarm)
+  hipStream_t get_ready(int i) {
+    if (s[i]) return s[i];
+    want_more.store(true, std::memory_order_relaxed);
+    return s[0];
+  }
+  static std::atomic<bool> want_more;
+  // create the missing streams and run a first (tiny) copy on each; the object must not be in use by a job
+  void warm_all() {
+    DeviceScope on(dev);
+    void* d = nullptr; void* h = nullptr;
+    if (hipMalloc(&d, 4096) != hipSuccess || hipHostMalloc(&h, 4096, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); }
+    for (int i = 0; i < 3; ++i) {
+      hipStream_t x = get(i);
+      if (x && d && h) { (void)hipMemcpyAsync(d, h, 4096, hipMemcpyHostToDevice, x); (void)hipMemcpyAsync(h, d, 4096, hipMemcpyDeviceToHost, x); (void)hipStreamSynchronize(x); }
+    }
+    if (d) (void)hipFree(d);
+    if (h) (void)hipHostFree(h);
+    (void)hipGetLastError();
+  }
   void sync_all() { for (auto& x : s) if (x) (void)hipStreamSynchronize(x); }
   ~Streams() {
     DeviceScope on(dev);
@@ -520,6 +534,7 @@ struct Streams {
   }
 };
 
+inline std::atomic<bool> Streams::want_more{false};
 inline std::vector<Streams*> g_stream_pool;
 
 struct StreamLease {     // borrow a ready-made set of streams of the CURRENT device, give it back on scope exit
@@ -556,5 +571,27 @@ struct DrainGuard {
   Streams* st;
   ~DrainGuard() { if (st) st->sync_all(); }
 };
+
+// What a call missed -- pinned staging blocks (PinnedBuf::fill_later), extra streams (Streams::get_ready) -- is set
+// up by ONE background thread that starts when the call is over (the entry points call this on their way out):
+// pinning takes the process's mmap lock and creating a queue takes 9 ms; done during the job both slowed it down.
+inline void kick_background() {
+  static std::atomic<bool> busy{false};
+  if (!PinnedBuf::fills_pending() && !Streams::want_more.load(std::memory_order_relaxed)) return;
+  if (busy.exchange(true)) return;
+  const int dev = current_device();
+  try {
+    std::thread([dev] {
+      (void)hipSetDevice(dev);
+      PinnedBuf::run_pending_fills();
+      if (Streams::want_more.exchange(false)) {
+        (void)hipSetDevice(dev);
+        StreamLease lease;                         // (taken out of the pool: no job uses it meanwhile)
+        if (lease.p) lease.p->warm_all();
+      }
+      busy = false;
+    }).detach();
+  } catch (...) { busy = false; }
+}
 
 }  // namespace qsx
