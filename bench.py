@@ -687,7 +687,11 @@ def run_colour(c):
         crop = [keep[0][: crop_c * 2].cpu().numpy(), keep[1][:crop_c].cpu().numpy(), keep[2][:crop_c].cpu().numpy()]
         kw = dict(hsamp=hsamp, vsamp=vsamp, colorspace=3, image_size=(size, crop_c * 16))
         if c["verify"]:
-            want = Oracle().do_quantsmooth(crop, quants, flags, args.niter, threads=0, **kw)
+            from oracle import oracle as om
+            truth = om.Reference("none") if om.have_ref("none") else Oracle()
+            res["verify_against"] = ("compiled reference (oracle/_ref/libqsref_none.so)" if om.have_ref("none")
+                                     else "plain-C port (oracle/libqs_oracle.so)")
+            want = truth.do_quantsmooth(crop, quants, flags, args.niter, threads=0, **kw)
             got = [band.eng[0].coef[: rows_c * 2].cpu().numpy()]
             for ci in (1, 2):
                 got.append((band.up[ci - 1][: rows_c * 2] if want["up"] else band.eng[ci].coef[:rows_c]).cpu().numpy())
