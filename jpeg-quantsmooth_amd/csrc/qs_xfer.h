@@ -526,6 +526,7 @@ struct Streams {
     if (h) (void)hipHostFree(h);
     (void)hipGetLastError();
   }
+  int count() const { return (s[0] != nullptr) + (s[1] != nullptr) + (s[2] != nullptr); }
   void sync_all() { for (auto& x : s) if (x) (void)hipStreamSynchronize(x); }
   ~Streams() {
     DeviceScope on(dev);
@@ -543,8 +544,10 @@ struct StreamLease {     // borrow a ready-made set of streams of the CURRENT de
     const int dev = current_device();
     {
       std::lock_guard<std::mutex> lk(g_cache_mu);
+      size_t best = g_stream_pool.size();          // of this device's sets, the one with the most queues
       for (size_t i = 0; i < g_stream_pool.size(); ++i)
-        if (g_stream_pool[i]->dev == dev) { p = g_stream_pool[i]; g_stream_pool.erase(g_stream_pool.begin() + i); return; }
+        if (g_stream_pool[i]->dev == dev && (best == g_stream_pool.size() || g_stream_pool[i]->count() > g_stream_pool[best]->count())) best = i;
+      if (best < g_stream_pool.size()) { p = g_stream_pool[best]; g_stream_pool.erase(g_stream_pool.begin() + best); return; }
     }
     Streams* n = new (std::nothrow) Streams;
     if (!n) return;
@@ -585,9 +588,20 @@ inline void kick_background() {
       (void)hipSetDevice(dev);
       PinnedBuf::run_pending_fills();
       if (Streams::want_more.exchange(false)) {
-        (void)hipSetDevice(dev);
-        StreamLease lease;                         // (taken out of the pool: no job uses it meanwhile)
-        if (lease.p) lease.p->warm_all();
+        // every pooled set of this device that lacks queues (taken out of the pool meanwhile: no job uses it)
+        for (;;) {
+          Streams* st = nullptr;
+          {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            for (size_t i = 0; i < g_stream_pool.size(); ++i)
+              if (g_stream_pool[i]->dev == dev && g_stream_pool[i]->count() < 3) { st = g_stream_pool[i]; g_stream_pool.erase(g_stream_pool.begin() + i); break; }
+          }
+          if (!st) break;
+          st->warm_all();
+          const bool done = st->count() == 3;
+          { std::lock_guard<std::mutex> lk(g_cache_mu); g_stream_pool.push_back(st); }
+          if (!done) break;                        // (queue creation failed: do not spin)
+        }
       }
       busy = false;
     }).detach();
