@@ -18,7 +18,7 @@ def run(name, coefs, quants, flags, niter, hsamp=None, vsamp=None, colorspace=No
     n = len(coefs)
     nblk = sum(c.shape[0] * c.shape[1] for c in coefs)
     ts = []
-    for rep in range(5):
+    for rep in range(8):
         job = hipqs.Job(); job.ncomp = n
         job.colorspace = colorspace if colorspace is not None else (3 if n == 3 else 1)
         work = [np.ascontiguousarray(c).copy() for c in coefs]
@@ -35,7 +35,8 @@ def run(name, coefs, quants, flags, niter, hsamp=None, vsamp=None, colorspace=No
         for j in range(2):
             if job.coef_up[j]: hip.lib.qs_hip_free(job.coef_up[j])
     best = min(ts[1:])
-    print(f"{name:46s} blocks={nblk:8d} first={ts[0]*1e3:8.2f} ms  steady={best*1e3:8.2f} ms  {nblk/best/1e6:8.2f} Mblocks/s (PCIe-inclusive)", flush=True)
+    print(f"{name:46s} blocks={nblk:8d} first={ts[0]*1e3:8.2f} ms  steady={best*1e3:8.2f} ms  {nblk/best/1e6:8.2f} Mblocks/s (PCIe-inclusive)"
+          f"   all: {' '.join('%.2f' % (t * 1e3) for t in ts)}", flush=True)
 
 c, q = synth.synth_gray(64, 64, 50); run("C0 64x64 gray q3 n3", [c], [q], 0, 3)
 j = synth.synth_ycc(1920, 1080, 2, 2, 50); kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(1920, 1080))

@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--jpeg-quality", type=int, default=50)
     a = ap.parse_args()
-    devices = [int(d) for d in a.devices.split(",") if d != ""]
+    devices = [int(d) for d in a.devices.replace("+", ",").split(",") if d != ""]   # ("+" works too: tools/session.sh turns commas into spaces)
     os.environ["QS_HIP_TRACE"] = "1"
     import torch
     import jpegqs_pkg
@@ -77,9 +77,10 @@ def main():
     sharded = len(devices) > 1
     one_ms, one, _ = call(False)                         # also the warm-up of device 0's pools
     times, traces, got = [], [], None
-    for rep in range(a.reps + 1):
+    warm = 3     # untimed: cold contexts and pools on the other devices; staging blocks and extra queues come up in the background
+    for rep in range(a.reps + warm):
         ms, got, tr = call(sharded)
-        if rep:                                          # first call on the other devices: cold contexts and pools
+        if rep >= warm:
             times.append(ms); traces.append(tr)
     out = {"entry": "qs_hip_do_quantsmooth_sharded" if sharded else "qs_hip_do_quantsmooth",
            "devices": devices, "image": f"{a.size}x{a.size} luma, q={a.quality} niter={a.niter}",
