@@ -89,6 +89,9 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra legs of the luma workload (single-plane latency, smooth input, the product's own multi-GPU route)")
+    ap.add_argument("--data", default="jpeg", choices=("jpeg", "synth"),
+                    help="jpeg (default): the synthetic image encoded by libjpeg and read back with jpeg_read_coefficients "
+                         "(falls back to synth when Pillow or tools/jpeg_coefs is missing); synth: float32-DCT coefficients built on the GPU")
     ap.add_argument("--input", default="survey", choices=("survey", "smooth"),
                     help="synthetic image: the SURVEY.md 8d formula (default) or its noise-free, ten times smoother variant")
     ap.add_argument("--verify", action="store_true", help="(default; kept for older command lines)")
@@ -100,10 +103,8 @@ def parse_args():
     return a
 
 
-def _synth_plane_gpu(torch, pkg, w, h, quant, dev, variant=0, seed=1234, squeeze=False, smooth=False):
-    """int16 [h/8, w/8, 64] quantised coefficients of the synthetic plane (formula of synth.py /
-    SURVEY.md 8d), float32 DCT via two small matmuls on the GPU"""
-    synth = pkg.synth
+def _synth_pixels_gpu(torch, w, h, dev, variant=0, seed=1234, squeeze=False, smooth=False):
+    """the synthetic image of SURVEY.md 8d (formula of synth.py) as a float tensor of integer pixel values 0..255"""
     g = torch.Generator(device=dev); g.manual_seed(seed + 7919 * variant)
     x = torch.arange(w, device=dev, dtype=torch.float32)[None, :]
     y = torch.arange(h, device=dev, dtype=torch.float32)[:, None]
@@ -121,12 +122,62 @@ def _synth_plane_gpu(torch, pkg, w, h, quant, dev, variant=0, seed=1234, squeeze
     img = img.round().clamp(0, 255)
     if squeeze:   # chroma is smoother and nearer mid-grey in natural images (synth.synth_ycc)
         img = (128 + torch.div(img - 128, 3, rounding_mode="floor")).clamp(0, 255)
-    img = img - 128.0
+    return img
+
+
+def _synth_plane_gpu(torch, pkg, w, h, quant, dev, variant=0, seed=1234, squeeze=False, smooth=False):
+    """int16 [h/8, w/8, 64] quantised coefficients of the synthetic plane, float32 DCT via two small matmuls on the
+    GPU (the fall-back input when the libjpeg route below is not available, and what the tests use)"""
+    synth = pkg.synth
+    img = _synth_pixels_gpu(torch, w, h, dev, variant, seed, squeeze, smooth) - 128.0
     d = torch.from_numpy(synth._dct_matrix().astype(np.float32)).to(dev)
     blk = img.reshape(h // 8, 8, w // 8, 8).permute(0, 2, 1, 3)
     c = d @ blk @ d.T
     q = torch.from_numpy(quant.astype(np.float32)).to(dev).reshape(8, 8)
     return torch.round(c / q).to(torch.int16).reshape(h // 8, w // 8, 64).contiguous()
+
+
+JPEG_COEFS = ROOT / "tools" / "jpeg_coefs"     # tools/jpeg_coefs.c, built by __graft_entry__.build()
+
+
+def jpeg_input(torch, size, jpeg_quality, dev, colour=False, smooth=False):
+    """BASELINE.md section 3's input: the synthetic image ENCODED BY LIBJPEG (Pillow: libjpeg-turbo, standard IJG tables at
+    `jpeg_quality`, baseline Huffman, integer DCT) and read back with jpeg_read_coefficients() -- what the jpegqs CLI hands to
+    do_quantsmooth.  -> ([coef tensors on the device], [quant tables]) or None when Pillow / the helper is missing."""
+    import subprocess
+    import tempfile
+    try:
+        from PIL import Image
+    except ImportError:
+        return None
+    if not JPEG_COEFS.exists():
+        return None
+    Image.MAX_IMAGE_PIXELS = None
+    planes = [_synth_pixels_gpu(torch, size, size, dev, variant=v, squeeze=v > 0, smooth=smooth).to(torch.uint8).cpu().numpy()
+              for v in (range(3) if colour else range(1))]
+    with tempfile.TemporaryDirectory() as tmp:
+        jpg, raw = Path(tmp) / "in.jpg", Path(tmp) / "in.bin"
+        if colour:
+            Image.merge("YCbCr", [Image.fromarray(p, "L") for p in planes]).save(jpg, quality=jpeg_quality, subsampling=2)
+        else:
+            Image.fromarray(planes[0], "L").save(jpg, quality=jpeg_quality)
+        if subprocess.run([str(JPEG_COEFS), str(jpg), str(raw)]).returncode != 0:
+            return None
+        b = raw.read_bytes()
+    hdr = np.frombuffer(b[:20], np.int32)
+    if hdr[0] != 0x51534a43:
+        return None
+    ncomp, off = int(hdr[1]), 20
+    geo, quants = [], []
+    for _ in range(ncomp):
+        geo.append(np.frombuffer(b[off:off + 20], np.int32)); off += 20
+        quants.append(np.frombuffer(b[off:off + 128], np.uint16).copy()); off += 128
+    coefs = []
+    for g in geo:
+        n = int(g[0]) * int(g[1]) * 64
+        coefs.append(torch.from_numpy(np.frombuffer(b[off:off + 2 * n], np.int16).reshape(int(g[1]), int(g[0]), 64).copy()).to(dev))
+        off += 2 * n
+    return coefs, quants
 
 
 def synth_input_gpu(torch, pkg, size, jpeg_quality, dev, smooth=False):
@@ -298,13 +349,18 @@ def main():
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["elapsed"] / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic",   # (a synthetic IMAGE; see config.workload for how it became coefficients)
             "mpixels_per_s": value * 64 / 1e6,
             "timed_region_s": res["elapsed"],
             "config": {"workload": res["workload"] +
-                       f", jpegqs --quality {args.quality} (flags={flags}) --niter {args.niter}; input = quantised float32-DCT "
-                       f"coefficients of the synthetic image of SURVEY.md 8d{' (smooth variant: periods x10, no noise)' if args.input == 'smooth' else ''} at JPEG quality {args.jpeg_quality} (built on the GPU; not "
-                       f"a libjpeg-encoded file, the CPU baseline consumes the same arrays)",
+                       f", jpegqs --quality {args.quality} (flags={flags}) --niter {args.niter}; input = the synthetic image of SURVEY.md 8d"
+                       f"{' (smooth variant: periods x10, no noise)' if args.input == 'smooth' else ''}, "
+                       + (f"ENCODED BY LIBJPEG (Pillow / libjpeg-turbo, standard tables at quality {args.jpeg_quality}, baseline, integer DCT) and "
+                          f"read back with jpeg_read_coefficients (tools/jpeg_coefs.c), as BASELINE.md section 3 asks"
+                          if ctx.get("data_note") == "libjpeg" else
+                          f"as quantised float32-DCT coefficients at JPEG quality {args.jpeg_quality} built on the GPU (not a libjpeg-encoded "
+                          f"file: Pillow or tools/jpeg_coefs missing, or --data synth)")
+                       + "; the CPU baseline consumes the same arrays",
                        "planes_per_step": res["batch"],
                        "sharding": "none" if world == 1 else f"{world} block-row bands, 1-pixel-row halo over "
                                                                f"{'RCCL' if args.backend == 'nccl' else 'gloo (host-staged)'} per iteration, "
@@ -376,7 +432,13 @@ def run_luma(c):
     r0, r1, hblk = topo.r0, topo.r1, topo.hblk
     total_blocks_plane = (hblk_total * wblk) * (world if args.weak else 1)
 
-    full, quant = synth_input_gpu(torch, pkg, size, args.jpeg_quality, dev, smooth=args.input == "smooth")
+    got = jpeg_input(torch, size, args.jpeg_quality, dev, smooth=args.input == "smooth") if args.data == "jpeg" else None
+    if got is not None:
+        full, quant = got[0][0], got[1][0]
+        c["data_note"] = "libjpeg"
+    else:
+        full, quant = synth_input_gpu(torch, pkg, size, args.jpeg_quality, dev, smooth=args.input == "smooth")
+        c["data_note"] = "synth"
     pristine = full[r0:r1].contiguous()
     nsteps = c["nsteps"]
     batch = _batch_size(args, nsteps, pristine.numel() * 2)
@@ -494,7 +556,8 @@ def run_luma(c):
         # (2) N = 1: the same workload on the smooth variant of the image (what the wave-uniform need_refresh skip is
         # worth on content that is not sensor noise; the headline input never lets a whole wave skip)
         if world == 1 and args.input == "survey":
-            sm, _ = synth_input_gpu(torch, pkg, size, args.jpeg_quality, dev, smooth=True)
+            got_s = jpeg_input(torch, size, args.jpeg_quality, dev, smooth=True) if c["data_note"] == "libjpeg" else None
+            sm = got_s[0][0] if got_s is not None else synth_input_gpu(torch, pkg, size, args.jpeg_quality, dev, smooth=True)[0]
             ks = max(2, min(args.steps, 5))
             ws = [[sm.clone() for _ in range(batch)] for _ in range(ks + 1)]
             one_step_sharded(ws[0])
@@ -599,7 +662,13 @@ def run_colour(c):
     args, torch, dist, pkg, hip, B = c["args"], c["torch"], c["dist"], c["pkg"], c["hip"], c["bands"]
     flags, size, world, rank, dev = c["flags"], c["size"], c["world"], c["rank"], c["dev"]
     hby, hbc, wby = size // 8, size // 16, size // 8
-    coefs, quants = synth_colour_gpu(torch, pkg, size, args.jpeg_quality, dev)
+    got = jpeg_input(torch, size, args.jpeg_quality, dev, colour=True) if args.data == "jpeg" else None
+    if got is not None:
+        coefs, quants = got
+        c["data_note"] = "libjpeg"
+    else:
+        coefs, quants = synth_colour_gpu(torch, pkg, size, args.jpeg_quality, dev)
+        c["data_note"] = "synth"
     hsamp, vsamp = [2, 1, 1], [2, 1, 1]
     if c["sharded"]:
         y0, y1, c0, c1 = B.colour_band_split(hby, hbc, 2, world)[rank]

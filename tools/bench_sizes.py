@@ -27,7 +27,7 @@ libs = [Path(p) for p in args.libs] or [pkg.lib_path()]
 dev = torch.device("cuda:0")
 full, quant = bench.synth_input_gpu(torch, pkg, 8192, 50, dev)
 wb = 1024
-rows = [int(r) for r in args.rows.split(",")]
+rows = [int(r) for r in args.rows.replace("+", ",").split(",")]
 print("flags", flags, "rows:", rows)
 for lib in libs:
     hip = pkg.HipQS(lib)
