@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--quality", type=int, default=3, choices=(3, 4))
     ap.add_argument("--niter", type=int, default=3)
-    ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--jpeg-quality", type=int, default=50)
     a = ap.parse_args()
     devices = [int(d) for d in a.devices.replace("+", ",").split(",") if d != ""]   # ("+" works too: tools/session.sh turns commas into spaces)
@@ -77,7 +77,7 @@ def main():
     sharded = len(devices) > 1
     one_ms, one, _ = call(False)                         # also the warm-up of device 0's pools
     times, traces, got = [], [], None
-    warm = 3     # untimed: cold contexts and pools on the other devices; staging blocks and extra queues come up in the background
+    warm = 6     # untimed: cold contexts and pools on the other devices; staging blocks and extra queues come up in the background
     for rep in range(a.reps + warm):
         ms, got, tr = call(sharded)
         if rep >= warm:
