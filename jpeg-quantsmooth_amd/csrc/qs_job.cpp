@@ -418,6 +418,22 @@ void warm_pools(std::vector<size_t> pinned, std::vector<size_t> device) {
 }
 }  // namespace
 
+// Process exit: the detached background threads (prewarm, kick_background) must not be inside a HIP call when the
+// HIP runtime's own static destructors run.  This library is unloaded before libamdhip64 (it depends on it), so its
+// static destructor is the place to wait for them (bounded: they finish in tens of milliseconds).
+namespace {
+struct BackgroundJoin {
+  ~BackgroundJoin() {
+    for (int i = 0; i < 5000; ++i) {
+      bool warm;
+      { std::lock_guard<std::mutex> lk(g_warm_mu); warm = g_warm_running != 0; }
+      if (!warm && !g_bg_busy.load()) return;
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+  }
+} g_background_join;
+}  // namespace
+
 void qsj::warm_wait() {
   std::unique_lock<std::mutex> lk(g_warm_mu);
   g_warm_cv.wait(lk, [] { return g_warm_running == 0; });

@@ -578,8 +578,9 @@ struct DrainGuard {
 // What a call missed -- pinned staging blocks (PinnedBuf::fill_later), extra streams (Streams::get_ready) -- is set
 // up by ONE background thread that starts when the call is over (the entry points call this on their way out):
 // pinning takes the process's mmap lock and creating a queue takes 9 ms; done during the job both slowed it down.
+inline std::atomic<bool> g_bg_busy{false};         // the background thread of kick_background is at work
 inline void kick_background() {
-  static std::atomic<bool> busy{false};
+  std::atomic<bool>& busy = g_bg_busy;
   if (!PinnedBuf::fills_pending() && !Streams::want_more.load(std::memory_order_relaxed)) return;
   if (busy.exchange(true)) return;
   const int dev = current_device();
