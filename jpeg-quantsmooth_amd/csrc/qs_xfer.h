@@ -580,9 +580,8 @@ struct DrainGuard {
 // pinning takes the process's mmap lock and creating a queue takes 9 ms; done during the job both slowed it down.
 inline std::atomic<bool> g_bg_busy{false};         // the background thread of kick_background is at work
 inline void kick_background() {
-  std::atomic<bool>& busy = g_bg_busy;
   if (!PinnedBuf::fills_pending() && !Streams::want_more.load(std::memory_order_relaxed)) return;
-  if (busy.exchange(true)) return;
+  if (g_bg_busy.exchange(true)) return;
   const int dev = current_device();
   try {
     std::thread([dev] {
@@ -604,9 +603,9 @@ inline void kick_background() {
           if (!done) break;                        // (queue creation failed: do not spin)
         }
       }
-      busy = false;
+      g_bg_busy = false;
     }).detach();
-  } catch (...) { busy = false; }
+  } catch (...) { g_bg_busy = false; }
 }
 
 }  // namespace qsx
