@@ -491,6 +491,7 @@ extern "C" void qs_hip_release_cache(void) {
   g_stream_pool.clear();
   for (auto& c : PinnedBuf::pool()) (void)hipHostFree(c.p);
   PinnedBuf::pool().clear();
+  PinnedBuf::pending().clear();                              // (blocks wanted for next time: not any more)
   if (cur != current_device()) (void)hipSetDevice(cur);
 }
 

@@ -139,6 +139,8 @@ struct DevBuf {
 // pageable D2H already runs at 55 GB/s.  So uploads above a few MiB go through a
 // pooled pinned staging buffer: four threads copy 8 MiB chunks into it and each
 // chunk's DMA is queued as soon as it is complete, overlapping the next copy.
+// (Round 3, tools/cold_phases: the BLOCKING hipMemcpy of pageable memory reaches 18-44 GB/s, so a large upload
+// is staged only when a pinned block of its size is already pooled -- see PinnedBuf::alloc(optional).)
 struct PinnedBuf {
   void* p = nullptr;
   size_t n = 0;
