@@ -27,12 +27,28 @@ One JSON line is printed by rank 0.  `roofline` is for the dominant kernel
 (qs_smooth_set_kernel, one launch = the 12 planes of a step): achieved = algorithmic bytes
 (256 B per block per launch: read + write of 64 int16) / mean launch time measured with HIP
 events on the launch stream.  The kernel is FP32-VALU-bound, so `roofline_valu` gives the fraction of the
-non-FMA FP32 vector peak, which is the roofline that actually binds.
-`verify_ok`: the last timed step's result is compared with the CPU oracle on 16 block
-rows at the top, in the middle and at the bottom of the plane (N > 1: also on the rows
-either side of every band edge).  `cpu_baseline` times the compiled reference
-(oracle/_ref, AVX-512 and AVX2 builds, OpenMP) over a sweep of thread counts on a bounded
-sample of the same workload on this box's host cores.
+non-FMA FP32 vector peak, which is the roofline that actually binds -- `frac` against the nominal
+78.6 T (2.0 cycles per instruction at 2.4 GHz), `frac_of_sustained` against the 68 T the chip sustains for a pure
+stream of this kernel's term instructions (profiles/valu_sustained.json, tools/ubench_clock.hip).
+
+Input (`--data jpeg`, the default): the synthetic image of SURVEY.md 8d ENCODED BY LIBJPEG (Pillow) and read back with
+jpeg_read_coefficients (tools/jpeg_coefs.c) -- BASELINE.md section 3; `--data synth` (and the fall-back when Pillow or
+the helper is missing): float32-DCT coefficients built on the GPU.  `config.workload` says which.
+
+`verify_ok`: the planes of the last timed step are compared with each other on the GPU, and the last one with the
+compiled reference (oracle/_ref/libqsref_none.so; the plain-C port when it did not travel) -- EVERY block at N = 1 up to
+8192^2 (`verify_rows` 1024), 16 block rows at the top / middle / bottom for larger planes, the top rows and both sides of
+every band edge for N > 1.  `cpu_baseline` times the compiled reference (AVX-512 and AVX2 builds, OpenMP) over a sweep
+of thread counts on a bounded sample of the same workload on this box's host cores.
+
+Extra legs of the luma workload (not part of `value`; `--no-extras` skips them):
+  single_plane_ms / value_batch1   ONE plane per step instead of twelve: single-image latency (N = 1) and single-image
+                                   strong scaling (N > 1: the RCCL halo exchange is paid per plane)
+  smooth_input                     N = 1: the same workload on the smooth variant of the image (periods x10, no noise),
+                                   where the wave-uniform need_refresh skip applies
+  product_route                    the PRODUCT's own multi-GPU route over the same N devices -- qs_hip_do_quantsmooth_sharded
+                                   (csrc/qs_shard.cpp: one process, peer copies), host arrays in and out, run as a child
+                                   process of rank 0 while the other ranks wait on a host-side (gloo) barrier
 """
 from __future__ import annotations
 
