@@ -498,6 +498,32 @@ def test_gpu_fuzz_corpus_every_pass_b_form(env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"QS_HIP_UPLOAD_STAGE": "0"}, {"QS_HIP_UPLOAD_STAGE": "1"}],
+                         ids=["large-uploads-never-staged", "uploads-always-staged"])
+def test_gpu_transfer_modes_full_size(env):
+    """the two upload policies behind QS_HIP_UPLOAD_STAGE (default: staged only when a pinned block is pooled, i.e. the
+    first call of a process uploads straight from caller memory and lands every result before writing any): an
+    8192 x 2048 plane through the banded fused route, twice in one process, and over three logical devices -- every
+    block against the oracle"""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+import jpegqs_pkg
+from oracle.oracle import Oracle
+pkg = jpegqs_pkg.load(); hip = pkg.HipQS(); O = Oracle()
+coef, quant = pkg.synth.synth_gray(8192, 6144, 50, seed=9)            # 786,432 blocks: three pipelined bands of 32 MiB
+want = O.do_quantsmooth([coef], [quant], 1, 2, threads=16)["coefs"][0]
+for rep in range(3):
+    got = hip.do_quantsmooth([coef], [quant], 1, 2)
+    assert got["ret"] == 0 and np.array_equal(got["coefs"][0], want), rep
+got = hip.do_quantsmooth([coef], [quant], 1, 2, devices=[0, 0, 0])
+assert np.array_equal(got["coefs"][0], want)
+print("ok")
+'''
+    assert "ok" in _run_py(code, env)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("size", [(65500, 8), (8, 65500), (65500, 24), (8, 8), (16, 16), (24, 8)])
 def test_gpu_extreme_geometry(gpu, oracle, synth, size):
     """JPEG's limits: the widest (8,188 blocks in one block row) and the tallest (8,188 block rows of
