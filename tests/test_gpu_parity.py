@@ -503,7 +503,7 @@ def test_gpu_fuzz_corpus_every_pass_b_form(env):
 def test_gpu_transfer_modes_full_size(env):
     """the two upload policies behind QS_HIP_UPLOAD_STAGE (default: staged only when a pinned block is pooled, i.e. the
     first call of a process uploads straight from caller memory and lands every result before writing any): an
-    8192 x 2048 plane through the banded fused route, twice in one process, and over three logical devices -- every
+    8192 x 6144 plane through the banded fused route, three times in one process, and over three logical devices -- every
     block against the oracle"""
     code = r'''
 import sys, numpy as np
