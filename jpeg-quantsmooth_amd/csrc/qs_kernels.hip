@@ -504,6 +504,25 @@ __device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >
             [q4] "v"((Q)[4]), [q5] "v"((Q)[5]), [q6] "v"((Q)[6]), [q7] "v"((Q)[7]), \
             [w0] "s"(W[(WO) + 0]), [w1] "s"(W[(WO) + 1]), [w2] "s"(W[(WO) + 2]), [w3] "s"(W[(WO) + 3]), \
             [w4] "s"(W[(WO) + 4]), [w5] "s"(W[(WO) + 5]), [w6] "s"(W[(WO) + 6]), [w7] "s"(W[(WO) + 7]), [r] "s"(Rs)); }
+// QS_EARLY_C0=1: the coefficient's LDS read is issued before the division of its update step (latency hiding)
+#ifndef QS_EARLY_C0
+#define QS_EARLY_C0 1
+#endif
+// QS_TIMELINE=1 (measurement builds only, tools/timeline.py): every wave of qs_smooth_plane_kernel accumulates the
+// shader cycles (s_memtime) it spends in the three phases of the coefficient walk -- refresh IDCT, term stream,
+// coefficient update -- plus its staging prologue and its whole life, and lane 0 stores them into a device buffer
+// registered through qs_hip_debug_timeline().  Each stamp is a scalar-memory read with its own wait (~3 % perturbation).
+#ifndef QS_TIMELINE
+#define QS_TIMELINE 0
+#endif
+#if QS_TIMELINE
+__device__ unsigned long long* qs_tl_buf = nullptr;
+#define QS_TL_NOW(T) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T) : : "memory")
+extern "C" int qs_hip_debug_timeline(void* dev_buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(dev_buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(qs_tl_buf), &p, sizeof p) == hipSuccess ? 0 : -1;
+}
+#endif
 // QS_SECTION_SPEC=1: the zero-weight skip is decided once per horizontal / vertical section (three
 // specialised copies of the section) instead of by a scalar compare-and-branch in front of 48 terms
 #ifndef QS_SECTION_SPEC
