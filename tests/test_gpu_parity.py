@@ -78,6 +78,54 @@ def test_gpu_colour_refresh_pass_sees_unclamped_coefficients(gpu, oracle, synth,
             assert_same_result(a, b, f"{size} {samp} flags={flags} niter={niter}")
 
 
+@pytest.mark.parametrize("env", [{}, {"QS_HIP_DP": "0"}, {"QS_HIP_DP_GROUPS": "100000"}],
+                         ids=["launcher's choice", "one-block-per-lane", "diagonal-parallel"])
+def test_gpu_refresh_skip_content(env):
+    """The need_refresh skip (reference quantsmooth.h:1407-1409; wave-uniform in the streaming kernel, workgroup-uniform
+    in the small-plane kernel) only fires when NO block of a wave changes a coefficient during an anti-diagonal -- which
+    the noisy synthetic images of the other tests almost never allow.  Content on which it fires all the time: flat
+    planes, gentle gradients, flat planes with a few textured blocks (skipping and non-skipping waves side by side, and
+    waves in which a single lane keeps the refresh alive), at several JPEG qualities, gray and 4:2:0, both kernels."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+import jpegqs_pkg
+from oracle.oracle import Oracle
+from helpers import assert_same_result
+pkg = jpegqs_pkg.load(); hip = pkg.HipQS(); O = Oracle(); S = pkg.synth
+rng = np.random.default_rng(5)
+def planes(w, h):
+    x = np.arange(w, dtype=np.float32)[None, :]; y = np.arange(h, dtype=np.float32)[:, None]
+    flat = np.full((h, w), 117.0, np.float32)
+    grad = 40.0 + 120.0 * x / w + 30.0 * np.sin(y / 97.0)
+    spots = flat.copy()
+    for _ in range(max(3, w * h // 40000)):
+        by, bx = int(rng.integers(0, h // 8)), int(rng.integers(0, w // 8))
+        spots[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] += rng.normal(0, 25, (8, 8))
+    steps = 128.0 + 60.0 * ((x // 64 + y // 48) % 2)
+    return {"flat": flat, "gradient": grad, "flat+textured blocks": spots, "steps": steps + 0 * y}
+for (w, h) in ((512, 136), (1024, 512), (2048, 1040)):
+    for name, img in planes(w, h).items():
+        pix = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        for qual in (30, 75, 95):
+            qt = S.quality_table(S.STD_LUMA, qual)
+            coef = S.quantise_plane(pix, qt)
+            for flags in (0, 1):
+                a = hip.do_quantsmooth([coef], [qt], flags, 3)
+                b = O.do_quantsmooth([coef], [qt], flags, 3, threads=8)
+                assert_same_result(a, b, f"{name} {w}x{h} q{qual} flags={flags}")
+# 4:2:0 colour, coupled flags: chroma planes are the smoothest content there is
+j = S.synth_ycc(640, 360, 2, 2, quality=60, seed=2)
+j["coefs"][1][:] = 0; j["coefs"][2][:, :, 1:] = 0
+kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(640, 360))
+for flags in (0, 1, 3, 7):
+    assert_same_result(hip.do_quantsmooth(j["coefs"], j["quants"], flags, 3, **kw),
+                       O.do_quantsmooth(j["coefs"], j["quants"], flags, 3, threads=8, **kw), f"ycc flags={flags}")
+print("ok")
+'''
+    assert "ok" in _run_py(code, env)
+
+
 def test_gpu_low_quality_gray(gpu, oracle, synth):
     for (w, h, qual) in ((64, 64, 50), (200, 120, 20), (24, 88, 92)):
         coef, quant = synth.synth_gray(w, h, qual, seed=5)
