@@ -138,3 +138,44 @@ def test_decode_mode_reports_a_backend_failure(hip):
     assert r.returncode == 3, (r.returncode, r.stderr.decode())
     assert b"no HIP device" in r.stderr and b"back end failed (status -1" in r.stderr
     assert r.stdout == b""
+
+
+def test_band_arithmetic_exported_from_c(hip):
+    """the ONE definition of the band split both multi-GPU drivers use (csrc/qs_planes.cpp): bands tile the rows
+    without gaps, colour bands keep luma and chroma on the same image rows, halo rows are the plane's first / last
+    pixel rows and its two apron rows"""
+    for hblk in (1, 7, 64, 135, 1024, 2048):
+        for n in (1, 2, 3, 8):
+            rows = [hip.band_rows(hblk, n, b) for b in range(n)]
+            assert rows[0][0] == 0 and rows[-1][1] == hblk
+            assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+            rows2 = [hip.band_rows(hblk, n, b, 2) for b in range(n)]
+            assert rows2[0][0] == 0 and rows2[-1][1] == hblk and all(r[0] % 2 == 0 for r in rows2)
+    for hby, hbc, vs in ((1024, 512, 2), (135, 68, 2), (135, 135, 1), (67, 34, 2)):
+        for n in (1, 2, 5, 8):
+            split = [hip.colour_band_rows(hby, hbc, vs, n, b) for b in range(n)]
+            assert split[0][0] == 0 and split[0][2] == 0 and split[-1][1] == hby and split[-1][3] == hbc
+            for (y0, y1, c0, c1), (y0n, _, c0n, _) in zip(split, split[1:]):
+                assert y1 == y0n and c1 == c0n and y0 == min(c0 * vs, hby)
+    with pytest.raises(Exception):
+        hip.band_rows(10, 0, 0)
+    for wblk, hblk in ((1, 1), (240, 17), (1024, 128)):
+        st, sb, rt, rb, n = hip.band_halo_rows(wblk, hblk)
+        assert n == hip.plane_pitch(wblk)
+        assert (st, sb, rt, rb) == tuple(hip.plane_row_offset(wblk, y) for y in (0, hblk * 8 - 1, -1, hblk * 8))
+
+
+def test_prewarm_is_harmless_without_a_device(pkg, hip, synth):
+    """qs_hip_prewarm returns at once, never fails loudly, and the next job-layer call waits for it: with no GPU the
+    call then reports QS_HIP_ENODEV as before (no hang, no crash); with one it simply works"""
+    import ctypes as C
+    assert hip.lib.qs_hip_prewarm(None, 0, 0) == 0
+    coef, quant = synth.synth_gray(64, 64, 50)
+    job, _ = hip._make_job([coef], [quant])
+    assert hip.lib.qs_hip_prewarm(C.byref(job), 0, 3) == 0
+    if hip.device_count() > 0:
+        assert hip.do_quantsmooth([coef], [quant], 0, 1)["ret"] == 0
+    else:
+        with pytest.raises(pkg.QsHipError) as ei:
+            hip.do_quantsmooth([coef], [quant], 0, 1)
+        assert ei.value.code == -1
