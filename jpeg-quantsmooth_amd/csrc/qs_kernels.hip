@@ -549,8 +549,10 @@ extern "C" int qs_hip_debug_timeline(void* dev_buf) {
 #endif
 // QS_SECTION_SPEC=1: the zero-weight skip is decided once per horizontal / vertical section (three
 // specialised copies of the section) instead of by a scalar compare-and-branch in front of 48 terms
+// (=1, one opaque asm block per term: +0.7 % before the phase priorities of QS_PHASE_PRIO -- inside the noise --, +2.1 % with
+//  them, 258.0 against 252.5-253.0 M blocks/s, and 4-5 % for a lone wave per SIMD; =2, one asm block per pixel row: 7 % slower)
 #ifndef QS_SECTION_SPEC
-#define QS_SECTION_SPEC 0
+#define QS_SECTION_SPEC 1
 #endif
 #ifndef QS_TAIL_PRIO
 #define QS_TAIL_PRIO 1
