@@ -286,8 +286,32 @@ def cpu_baseline(args, run_sample, total_units, unit_name, describe):
 
 # ---------------------------------------------------------------------------
 
+def _self_launch(args):
+    """`python bench.py --gpus N` started plainly (no launcher in the environment) becomes the N-rank job itself: the
+    process is REPLACED by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`
+    (one rank per GPU over RCCL; rendezvous on 127.0.0.1 and a free port), so that one command is the whole benchmark,
+    like the reference's one call that fans out over OpenMP threads (quantsmooth.h:2587-2640)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")                 # (what torchrun would set, without its warning)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    print("bench.py: --gpus %d without a launcher: re-executing as `%s`" % (args.gpus, " ".join(cmd[1:])), file=sys.stderr, flush=True)
+    os.execve(sys.executable, cmd, env)
+
+
+def _needs_self_launch(args, environ):
+    return args.gpus > 1 and "WORLD_SIZE" not in environ and "RANK" not in environ
+
+
 def main():
     args = parse_args()
+    if _needs_self_launch(args, os.environ):
+        _self_launch(args)           # does not return
     import torch
     import torch.distributed as dist
 
@@ -295,12 +319,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE={world})", file=sys.stderr)
-            sys.exit(2)
-        args.gpus = world
+        args.gpus = world            # started by a launcher: its world size is the truth
     if args.single_device:
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        print(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} HIP device(s) visible "
+              f"(--single-device --backend gloo runs all ranks on one GPU as a functional test)", file=sys.stderr)
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm_note = None
@@ -345,16 +370,21 @@ def main():
         kblocks = res["kernel_blocks"]
         achieved_gbs = kblocks * ALGO_BYTES_PER_BLOCK_ITER / (kern_ms * 1e-3) / 1e9
         achieved_tf = kblocks * FLOP_PER_BLOCK_ITER[flags & 1] / (kern_ms * 1e-3) / 1e12
+        # `traffic` is NOT measured by this run: it is the PMC figure (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the
+        # gfx950 corrections of MI355X_MICROARCH.md) of an earlier profiled run of the same command, kept in
+        # profiles/pmc_traffic.json; `traffic_measured_in` names the profile folder it came from, so a stale figure is visible.
         traffic, traffic_src = None, None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists() and not colour and world == 1:
             try:
                 j = json.loads(pmc.read_text())
                 ppl = res.get("planes_per_launch", 1)
+                det = j.get(f"set{ppl}_detail", {}).get(f"q{args.quality}", {}) if ppl > 1 else {}
                 traffic = j.get(f"q{args.quality}_{size}_set{ppl}") if ppl > 1 else None
-                traffic_src = j.get("_source")
+                traffic_src = det.get("measured_in") or j.get("_source")
                 if traffic is None:
                     traffic = j.get(f"q{args.quality}_{size}")
+                    traffic_src = j.get("_source")
                     if traffic is not None and ppl > 1:           # only single-plane counters on file
                         traffic *= ppl
                         traffic_src = f"{ppl} x the per-plane figure of " + str(traffic_src)
@@ -388,7 +418,9 @@ def main():
                        "blocks_per_gpu": res["blocks_per_gpu"], **({"comm_note": comm_note} if comm_note else {})},
             "roofline": {"bound": "hbm", "kernel": res["kernel"], "achieved": achieved_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
+                         "traffic": traffic, "traffic_measured_in": traffic_src,
+                         "traffic_kind": "PMC counters of an earlier profiled run of this command (profiles/pmc_traffic.json); not re-measured by this run",
+                         "kernel_ms": kern_ms,
                          "kernel_launches_timed": res["kernel_launches"],
                          "algorithmic_bytes_per_launch": kblocks * ALGO_BYTES_PER_BLOCK_ITER,
                          "planes_per_launch": res.get("planes_per_launch", 1),
@@ -399,7 +431,7 @@ def main():
                               "flop_per_block_iter": FLOP_PER_BLOCK_ITER[flags & 1],
                               **_sustained(achieved_tf)},
         }
-        for k in ("single_plane_ms", "value_batch1", "planes_identical", "smooth_input", "product_route", "verify_against"):
+        for k in ("single_plane_ms", "value_batch1", "planes_identical", "smooth_input", "scaling_emulation", "product_route", "verify_against"):
             if res.get(k) is not None:
                 out[k] = res[k]
         for k in ("verify_ok", "verify_rows", "verify_detail", "verify_band_edges_ok"):
@@ -431,6 +463,51 @@ def _max_over_ranks(torch, dist, world, elapsed, dev, backend):
 def _batch_size(args, nsteps, bytes_per_plane):
     want = args.batch if args.batch > 0 else 12
     return max(1, min(want, RESIDENT_BUDGET // max(1, nsteps * bytes_per_plane)))
+
+
+def _scaling_emulation(torch, hip, bands, full, quant, flags, niter, dev, hblk_total, steps=8):
+    """ms per single-image step of the middle 1/N band for N = 1, 2, 4, 8 (batch = 1: one plane, one launch per pass),
+    the mean pass-B launch time by HIP events, and the implied speed-up over N = 1"""
+    out = {"what": "one rank's share of a single-image N-GPU step on THIS GPU: middle 1/N band of one plane, "
+                   "niter x {pass A, 2 halo rows in + out as device copies, pass B}; no interconnect latency",
+           "ms_per_step": {}, "pass_b_us": {}, "speedup_vs_1": {}}
+    stream = torch.cuda.current_stream()
+    for n in (1, 2, 4, 8):
+        if n == 1:
+            topo = bands.BandTopology(0, 1, 0, hblk_total)
+        else:
+            r = n // 2
+            r0, r1 = bands.band_rows(hblk_total, n, r)
+            topo = bands.BandTopology(r, n, r0, r1)
+        src = full[topo.r0:topo.r1].contiguous()
+        work = [src.clone() for _ in range(steps + 2)]
+        eng = bands.HipBandEngine(hip, torch, work[0], quant, flags, luma=1, device=dev)
+        h = eng.hblk * 8
+
+        def fake_exchange():
+            if n > 1:                                    # same bytes as the real exchange, both directions
+                eng.row(-1).copy_(eng.row(0)); eng.row(h).copy_(eng.row(h - 1))
+        pairs, pend = [], []
+
+        def mark(which):
+            ev = torch.cuda.Event(enable_timing=True); ev.record(stream)
+            if which == 0:
+                pend.append(ev)
+            else:
+                pairs.append((pend.pop(), ev))
+        for i, p in enumerate(work):
+            if i == 2:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            eng.rebind(p)
+            bands.run_bands_batched_sets(hip, [eng], topo, niter, fake_exchange, mark=mark if i >= 2 else None)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out["ms_per_step"][str(n)] = ms
+        out["pass_b_us"][str(n)] = float(np.mean([a.elapsed_time(b) for a, b in pairs])) * 1e3
+        del work, eng
+    for n in ("2", "4", "8"):
+        out["speedup_vs_1"][n] = out["ms_per_step"]["1"] / out["ms_per_step"][n]
+    return out
 
 
 # ---------------------------------------------------------------------------
@@ -587,6 +664,13 @@ def run_luma(c):
                           "steps": ks, "input": "SURVEY.md 8d formula with every period x10 and no noise"}
             del ws, sm
 
+    # (3) N = 1: what ONE rank of an N-GPU run of a SINGLE image does per step, emulated here -- the middle 1/N band of one
+    # plane, niter x {pass A, halo rows, pass B}, the halo exchange replaced by device copies of the same rows.  Device
+    # side only (no interconnect latency): an upper bound on single-image strong scaling, reported every round.
+    scaling_emu = None
+    if engs and not args.no_extras and world == 1 and hblk_total >= 64:
+        scaling_emu = _scaling_emulation(torch, hip, bands, pristine, quant, flags, args.niter, dev, hblk_total)
+
     set_launch = engs is not None                         # the timed launches cover all planes of the step
     res = dict(elapsed=elapsed, batch=batch, total_blocks=total_blocks_plane * batch, blocks_per_gpu=hblk * wblk,
                kernel=(f"qs_smooth_set_kernel<{'true' if flags & 1 else 'false'}> (one launch = the {batch} planes of a step)"
@@ -598,7 +682,7 @@ def run_luma(c):
                kernel_launches=len(ev_pairs),
                workload=f"{size}x{size} luma plane ({hblk_total * wblk} blocks)",
                planes_identical=planes_identical, single_plane_ms=single_plane_ms, value_batch1=value_batch1,
-               smooth_input=smooth_res)
+               smooth_input=smooth_res, scaling_emulation=scaling_emu)
     if c["verify"] and c["sharded"]:
         from oracle.oracle import Oracle
         got = last.cpu().numpy()

@@ -1,4 +1,9 @@
 /*
+ * JPEG Quant Smooth API definitions
+ * Copyright (C) 2020-2026 Ilya Kurdyukov  (the API below -- names, enum values,
+ * struct layout, prototypes -- is that of the reference's libjpegqs.h, LGPL-2.1;
+ * the attribution stays with it)
+ *
  * libjpegqs.h -- the JPEG Quant Smooth library API, as implemented by the
  * MI355X (gfx950) build in this repository.
  *

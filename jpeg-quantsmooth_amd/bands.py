@@ -27,19 +27,45 @@ _LIB = None
 def _lib():
     """the product library: the band arithmetic below is ITS definition (csrc/qs_planes.cpp:
     qs_hip_band_rows / qs_hip_colour_band_rows / qs_hip_band_halo_rows), shared with the in-process
-    multi-GPU route csrc/qs_shard.cpp -- this driver only adds the transport (torch.distributed)"""
+    multi-GPU route csrc/qs_shard.cpp -- this driver only adds the transport (torch.distributed).
+    None when the library cannot be loaded (a CPU-only box without the HIP runtime): the two pure
+    integer functions then fall back to the Python restatement below, which tests/test_bands.py
+    pins to the C definition value for value wherever the library does load."""
     global _LIB
     if _LIB is None:
-        from .hipqs import HipQS
-        _LIB = HipQS()
-    return _LIB
+        try:
+            from .hipqs import HipQS
+            _LIB = HipQS()
+        except (OSError, RuntimeError, ImportError):
+            _LIB = False
+    return _LIB or None
+
+
+def _band_rows_py(hblk: int, world: int, rank: int, align: int = 1):
+    """qs_hip_band_rows restated (integer arithmetic only; no compute)"""
+    if hblk < 0 or world < 1 or not 0 <= rank < world or align < 1:
+        raise ValueError("band_rows: bad argument")
+    units = (hblk + align - 1) // align
+    a, b = units * rank // world * align, units * (rank + 1) // world * align
+    return min(a, hblk), min(b, hblk)
+
+
+def _colour_band_rows_py(hblk_y: int, hblk_c: int, vs: int, world: int, rank: int):
+    """qs_hip_colour_band_rows restated"""
+    if vs < 1:
+        raise ValueError("colour_band_rows: bad argument")
+    c0, c1 = _band_rows_py(hblk_c, world, rank, 1)
+    y0 = min(c0 * vs, hblk_y)
+    y1 = hblk_y if rank == world - 1 else min(c1 * vs, hblk_y)
+    return y0, y1, c0, c1
 
 
 def band_rows(hblk: int, world: int, rank: int, align: int = 1):
     """block rows [r0, r1) owned by `rank`; band edges fall on multiples of
     `align` block rows (2 for the luma plane of a 4:2:0 image so that chroma
     bands line up with luma bands).  C: qs_hip_band_rows."""
-    return _lib().band_rows(hblk, world, rank, align)
+    lib = _lib()
+    return lib.band_rows(hblk, world, rank, align) if lib else _band_rows_py(hblk, world, rank, align)
 
 
 @dataclass
@@ -554,7 +580,9 @@ def exchange_rows_dist_hostcopy(rows: PlaneRows, topo: BandTopology, dist) -> No
 
 def colour_band_split(hblk_y, hblk_c, vs, world):
     """[(luma r0, r1, chroma r0, r1)] per rank; cut on chroma block rows.  C: qs_hip_colour_band_rows."""
-    return [_lib().colour_band_rows(hblk_y, hblk_c, vs, world, r) for r in range(world)]
+    lib = _lib()
+    return [lib.colour_band_rows(hblk_y, hblk_c, vs, world, r) if lib else _colour_band_rows_py(hblk_y, hblk_c, vs, world, r)
+            for r in range(world)]
 
 
 def run_colour_band_dist(band: ColourBand, dist) -> None:

@@ -249,39 +249,29 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
     for (int ci = 0; ci < 3; ++ci)
       host_pieces(jobs[which[g]], ci, 0, jobs[which[g]]->hblk[ci], cj[g].coef_off[ci], back);
   }
-  if (!stage.p) {                                            // no restore copy: everything lands before anything is written
-    HIP_TRY(down.land(coef.p, s));
-    for (int g = 0; g < G; ++g)
-      for (int k = 0; k < 2 && cj[g].upsample; ++k)
-        HIP_TRY(down_up_of[(size_t)g * 2 + k]->land(upc.as<char>() + cj[g].upc_off[k], s));
-  }
-  if (hipError_t e = down.finish(coef.p, back, s)) {          // a late failure: put the original blocks back
-    (void)hipStreamSynchronize(s);
-    if (stage.p) for (const Piece& pc : back) memcpy(pc.host, static_cast<const char*>(stage.p) + pc.off, pc.len);
-    return qs_fail(QS_HIP_ENODEV, "download failed: %s", hipGetErrorString(e));
-  }
-  // replacement arrays: first every transfer is completed (nothing handed out yet, so an error on the
-  // way leaves no job half-updated), then ownership moves to the jobs
-  struct UpArrays {
-    std::vector<int16_t*> p;
-    ~UpArrays() { for (int16_t* q : p) if (q) free(q); }                    // (only malloc'ed ones are kept here)
-  } ups;
-  ups.p.assign((size_t)G * 2, nullptr);
-  for (int g = 0; g < G; ++g) {
-    if (!cj[g].upsample) continue;
-    const bool bad = (hst[g * 3] | hst[g * 3 + 1] | hst[g * 3 + 2]) != 0;
-    for (int k = 0; k < 2; ++k) {
-      Download& D = *down_up_of[(size_t)g * 2 + k];
-      const char* src = upc.as<char>() + cj[g].upc_off[k];
-      if (D.staged) {
-        HIP_TRY(D.finish(src, std::vector<Piece>{}, s));                    // (waits for its chunks)
-      } else if (!bad) {
-        int16_t* q = static_cast<int16_t*>(malloc(cj[g].ubytes));
-        if (!q) return qs_fail(QS_HIP_ENOMEM, "out of host memory");
-        ups.p[(size_t)g * 2 + k] = q;
-        HIP_TRY(D.finish(src, std::vector<Piece>{{q, 0, cj[g].ubytes}}, s));
+  // A failure from here on must leave every job as it came in.  With a restore copy (the upload staging) the caller's
+  // blocks are put back on any error exit below; without one, everything -- the coefficients and the replacement
+  // arrays -- lands in library-owned host memory BEFORE the first byte of the caller's is written, and nothing can
+  // fail after that.
+  auto land_up = [&]() -> hipError_t {                       // replacement arrays into pinned staging / malloc'ed landing buffers
+    for (int g = 0; g < G; ++g) {
+      if (!cj[g].upsample) continue;
+      const bool bad = (hst[g * 3] | hst[g * 3 + 1] | hst[g * 3 + 2]) != 0;
+      for (int k = 0; k < 2; ++k) {
+        Download& D = *down_up_of[(size_t)g * 2 + k];
+        if (D.staged || !bad)
+          if (hipError_t e = D.land(upc.as<char>() + cj[g].upc_off[k], s)) return e;
       }
     }
+    return hipSuccess;
+  };
+  if (!stage.p) { HIP_TRY(down.land(coef.p, s)); HIP_TRY(land_up()); }
+  hipError_t e = down.finish(coef.p, back, s, stage.p != nullptr);               // scatter, chunk by chunk as the chunks arrive
+  if (e == hipSuccess) e = land_up();                        // (with a restore copy: overlapped with the scatter above)
+  if (e != hipSuccess) {                                     // a late failure: put the original blocks back
+    (void)hipStreamSynchronize(s);
+    if (stage.p) for (const Piece& pc : back) memcpy(pc.host, static_cast<const char*>(stage.p) + pc.off, pc.len);
+    return qs_fail(e == hipErrorOutOfMemory ? QS_HIP_ENOMEM : QS_HIP_ENODEV, "download failed: %s", hipGetErrorString(e));
   }
   for (int g = 0; g < G; ++g) {
     qs_hip_job* job = jobs[which[g]];
@@ -290,8 +280,8 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
       for (int k = 0; k < 2; ++k) {
         Download& D = *down_up_of[(size_t)g * 2 + k];
         // a staged array IS the pinned download buffer: it changes owner (qs_hip_free gives it back to the pool)
-        job->coef_up[k] = D.staged ? static_cast<int16_t*>(pinned_handout(D.stage)) : ups.p[(size_t)g * 2 + k];
-        ups.p[(size_t)g * 2 + k] = nullptr;
+        // ... an unstaged one is its malloc'ed landing buffer
+        job->coef_up[k] = static_cast<int16_t*>(D.staged ? pinned_handout(D.stage) : D.take_landed());
       }
       job->up_wblk = job->wblk[0]; job->up_hblk = job->hblk[0];
       job->out_hsamp0 = job->out_vsamp0 = 1;

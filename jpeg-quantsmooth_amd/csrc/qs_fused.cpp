@@ -224,7 +224,7 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
     for (const FPlane& P : G.planes)
       if (!bad_job[P.job]) { result_pieces(P, back); scattered[P.job] = 1; }
     if (!G.stage.p) HIP_TRY(G.down.land(G.coef.p, G.s));        // no restore copy: land first, write afterwards
-    HIP_TRY(G.down.finish(G.coef.p, back, G.s));
+    HIP_TRY(G.down.finish(G.coef.p, back, G.s, G.stage.p != nullptr));
     for (int ji : G.jobs) ++ndone[ji];
     // the group's stream work is complete: recycle its device arenas and download staging now, so
     // that memory in flight is bounded by the window below and not by the size of the batch.  The

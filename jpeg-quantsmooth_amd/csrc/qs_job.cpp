@@ -282,7 +282,7 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
       if (!C.processed) continue;
       std::vector<Piece> dst;
       host_pieces(job, ci, 0, job->hblk[ci], 0, dst);
-      HIP_TRY(C.down.finish(C.coef.p, dst, C.stream));
+      HIP_TRY(C.down.finish(C.coef.p, dst, C.stream, have_copy));
       if (C.have_up && !stop) {
         if (C.down_up.staged) {
           // the replacement array IS the pinned download buffer: it changes owner (qs_hip_free gives it
@@ -373,7 +373,16 @@ namespace {
 std::mutex g_warm_mu;
 std::condition_variable g_warm_cv;
 int g_warm_running = 0;                 // prewarm threads at work (guarded by g_warm_mu)
-std::once_flag g_warm_runtime_once;
+unsigned long long g_warm_runtime_done = 0;   // bit d: device d's context / queues / code object were warmed (guarded by g_warm_mu)
+
+// the runtime part of the warm-up runs once PER DEVICE (contexts, queues and the code object are per device)
+bool warm_runtime_claim(int dev) {
+  std::lock_guard<std::mutex> lk(g_warm_mu);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (g_warm_runtime_done & bit) return false;
+  g_warm_runtime_done |= bit;
+  return true;
+}
 
 void warm_runtime() {
   int n = 0;
@@ -463,16 +472,30 @@ extern "C" int qs_hip_prewarm(const qs_hip_job* geometry, int flags, int niter) 
           for (int k = 0; k < 2; ++k) sizes.push_back((size_t)g.wblk[0] * g.hblk[0] * 128);   // the replacement arrays
       }
     }
-    { std::lock_guard<std::mutex> lk(g_warm_mu); ++g_warm_running; }
-    std::thread([sizes, device]() {
+    // The warm-up belongs to the CALLER's device: a new thread starts on HIP device 0, and the stream pool, the device
+    // arenas and the context are all keyed on the current device -- warming device 0 for a caller that works on device
+    // 3 would create a context and cache up to an image of memory on another worker's GPU and leave the caller's cold.
+    const int dev = current_device();
+    // "a prewarm thread is at work" is counted before the thread exists and given back on EVERY path on which the
+    // thread does not come to exist (std::system_error from the constructor, bad_alloc copying the captures): a count
+    // left behind would block every later warm_wait() -- i.e. every later job -- forever.
+    struct WarmCount {
+      bool armed = true;
+      WarmCount() { std::lock_guard<std::mutex> lk(g_warm_mu); ++g_warm_running; }
+      static void done() { { std::lock_guard<std::mutex> lk(g_warm_mu); --g_warm_running; } g_warm_cv.notify_all(); }
+      ~WarmCount() { if (armed) done(); }
+    } count;
+    std::thread([sizes, device, dev]() {
       try {
-        std::call_once(g_warm_runtime_once, warm_runtime);
         int n = 0;
-        if (!sizes.empty() && hipGetDeviceCount(&n) == hipSuccess && n > 0) warm_pools(sizes, device);
+        if (hipGetDeviceCount(&n) == hipSuccess && n > 0 && hipSetDevice(dev) == hipSuccess) {
+          if (warm_runtime_claim(dev)) warm_runtime();
+          if (!sizes.empty()) warm_pools(sizes, device);
+        } else (void)hipGetLastError();
       } catch (...) {}
-      { std::lock_guard<std::mutex> lk(g_warm_mu); --g_warm_running; }
-      g_warm_cv.notify_all();
+      WarmCount::done();
     }).detach();
+    count.armed = false;                                     // the thread owns the count now
     return QS_HIP_OK;
   } catch (...) {
     return QS_HIP_ENOMEM;                                    // (no thread, no memory: the job will simply start cold)

@@ -355,7 +355,7 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
     std::vector<Piece> back;
     for (const BandPlane& P : B.planes)
       host_pieces(job, P.ci, P.r0, P.hb, P.coef_off, back);
-    HIP_TRY_RESTORE(B.down.finish(B.coef.p, back, B.s));
+    HIP_TRY_RESTORE(B.down.finish(B.coef.p, back, B.s, B.stage.p != nullptr));
   }
   if (trace_on()) {
     // device time of the iterations per band (kernels + halo pulls + waiting for the neighbours), by HIP events
@@ -551,7 +551,7 @@ static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::
     std::vector<Piece> back;
     for (const BandPlane& P : B.planes)
       host_pieces(job, P.ci, P.r0, P.hb, P.coef_off, back);
-    HIP_TRY_RESTORE(B.down.finish(B.coef.p, back, B.s));
+    HIP_TRY_RESTORE(B.down.finish(B.coef.p, back, B.s, B.stage.p != nullptr));
     if (upsample)
       for (int j = 0; j < 2; ++j) {
         const BandPlane& Y = B.planes[0];

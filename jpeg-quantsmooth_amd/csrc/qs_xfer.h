@@ -28,7 +28,7 @@ namespace qsx {
 
 struct CacheEntry { void* p; size_t n; int dev; };
 inline std::mutex g_cache_mu;
-inline std::vector<CacheEntry> g_cache;            // free device blocks (all devices)
+inline std::vector<CacheEntry>& g_cache = *new std::vector<CacheEntry>;   // free device blocks (all devices); leaked: see PinnedBuf::pool()
 inline const size_t kCacheMaxBytes = (size_t)6 << 30;   // per device
 
 inline int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; } return d; }
@@ -148,7 +148,11 @@ struct PinnedBuf {
   PinnedBuf(const PinnedBuf&) = delete;
   PinnedBuf& operator=(const PinnedBuf&) = delete;
   ~PinnedBuf() { release(); }
-  static std::vector<CacheEntry>& pool() { static std::vector<CacheEntry> v; return v; }   // (inline function: one per library)
+  // (inline function: one per library.  Leaked on purpose, like pending() and pinned_handouts() below: function-local
+  //  statics are destroyed BEFORE the namespace-scope object that joins the background threads at exit (qs_job.cpp:
+  //  BackgroundJoin) when they were constructed after it, and a prewarm / kick_background thread still at work would
+  //  then touch a dead container.)
+  static std::vector<CacheEntry>& pool() { static auto* v = new std::vector<CacheEntry>; return *v; }
   // optional: the caller has a fall-back that costs less than pinning a large block NOW (an upload can go
   // straight from pageable memory at ~44 GB/s on this platform, pinning costs ~0.18 ms per MiB): a block above
   // kOptionalMax is then only taken from the pool, and one is pinned in the background for the next call
@@ -182,7 +186,7 @@ struct PinnedBuf {
   // Blocks wanted for next time.  They are pinned by ONE background thread that starts when the job that missed
   // them has finished (kick_fills, called by the entry points on their way out): pinning takes the process's
   // mmap lock, and done during the job it slowed the job's own pageable copies down to a third.
-  static std::vector<std::pair<size_t, int>>& pending() { static std::vector<std::pair<size_t, int>> v; return v; }
+  static std::vector<std::pair<size_t, int>>& pending() { static auto* v = new std::vector<std::pair<size_t, int>>; return *v; }
   static void fill_later(size_t want) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     if (pending().size() < 16) pending().push_back({want, current_device()});
@@ -222,7 +226,7 @@ struct PinnedBuf {
 // Pinned blocks handed to the caller as result arrays (qs_hip_job::coef_up): the download staging
 // buffer itself changes owner instead of being copied into freshly malloc'ed (page-faulting)
 // memory; qs_hip_free() recognises such a block and puts it back into the pinned pool.
-inline std::vector<CacheEntry>& pinned_handouts() { static std::vector<CacheEntry> v; return v; }
+inline std::vector<CacheEntry>& pinned_handouts() { static auto* v = new std::vector<CacheEntry>; return *v; }
 inline void* pinned_handout(PinnedBuf& b) {
   std::lock_guard<std::mutex> lk(g_cache_mu);
   pinned_handouts().push_back({b.p, b.n, -1});
@@ -439,6 +443,7 @@ struct Download {
     if (staged) {
       for (size_t c = 0; c < ev.size() && e == hipSuccess; ++c) e = hipEventSynchronize(ev[c]);
     } else if (bytes) {
+      free(tmp);                                    // (a retry after a failed land must not leak the earlier buffer)
       tmp = malloc(bytes);
       if (!tmp) return hipErrorOutOfMemory;
       e = hipStreamSynchronize(s);                  // then the blocking copy: the fast pageable path (see upload_pieces)
@@ -450,6 +455,8 @@ struct Download {
     landed = e == hipSuccess;
     return e;
   }
+  // the malloc'ed landing buffer of an unstaged, landed download changes owner (free() releases it)
+  void* take_landed() { void* q = landed && !staged ? tmp : nullptr; if (q) tmp = nullptr; return q; }
   // landed bytes -> the caller's pieces: host copies only, cannot fail
   void scatter(const std::vector<Piece>& pieces) {
     if (!landed || pieces.empty() || !bytes) return;
@@ -462,7 +469,18 @@ struct Download {
   }
 
   // overlapped form (see above): land-and-scatter chunk by chunk
-  hipError_t finish(const void* src, const std::vector<Piece>& pieces, hipStream_t s) {
+  // have_restore: the caller can put the pieces back should this fail half-way (it holds the pinned upload staging):
+  // an UNSTAGED download (small, or pinned memory exhausted) then goes straight into the pieces, one blocking copy
+  // each, instead of through a full-size temporary and a second host copy
+  hipError_t finish(const void* src, const std::vector<Piece>& pieces, hipStream_t s, bool have_restore = false) {
+    if (!staged && !landed && have_restore && bytes && !pieces.empty()) {
+      hipError_t e = hipStreamSynchronize(s);
+      for (size_t i = 0; i < pieces.size() && e == hipSuccess; ++i)
+        e = hipMemcpy(pieces[i].host, static_cast<const char*>(src) + pieces[i].off, pieces[i].len, hipMemcpyDeviceToHost);
+      if (e == hipSuccess && test_fail_finish()) e = hipErrorUnknown;      // (test hook: fails AFTER the pieces were written)
+      landed = e == hipSuccess;
+      return e;
+    }
     if (!staged || landed) {
       hipError_t e = land(src, s);
       if (e == hipSuccess) scatter(pieces);
@@ -538,7 +556,7 @@ struct Streams {
 };
 
 inline std::atomic<bool> Streams::want_more{false};
-inline std::vector<Streams*> g_stream_pool;
+inline std::vector<Streams*>& g_stream_pool = *new std::vector<Streams*>;   // (leaked on purpose, see PinnedBuf::pool())
 
 struct StreamLease {     // borrow a ready-made set of streams of the CURRENT device, give it back on scope exit
   Streams* p = nullptr;

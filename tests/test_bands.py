@@ -11,6 +11,22 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
+def test_band_rows_python_restatement_equals_c(pkg):
+    """bands.py's fall-back for boxes where the product library cannot be loaded is pinned to the C definition"""
+    from jpeg_quantsmooth_amd import bands as B
+    lib = B._lib()
+    assert lib is not None, "the product library must load here (it carries the definition)"
+    for hblk in (0, 1, 7, 8, 25, 128, 1024, 2047):
+        for world in (1, 2, 3, 4, 8, 13):
+            for align in (1, 2, 4):
+                for r in range(world):
+                    assert B._band_rows_py(hblk, world, r, align) == lib.band_rows(hblk, world, r, align)
+    for hy, hc, vs in ((1024, 512, 2), (135, 68, 2), (9, 9, 1), (17, 5, 4), (64, 64, 1)):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                assert B._colour_band_rows_py(hy, hc, vs, world, r) == lib.colour_band_rows(hy, hc, vs, world, r)
+
+
 def test_band_rows_cover_and_align(pkg):
     from jpeg_quantsmooth_amd.bands import band_rows
     for hblk in (1, 2, 7, 64, 135, 1024, 2048):
@@ -254,6 +270,56 @@ def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
         assert pr.get("error") is None, pr
         assert pr["entry"] == "qs_hip_do_quantsmooth_sharded" and pr["devices"] == [0, 0]
         assert pr["equals_one_device_result"] is True and pr["verify_ok"] is True
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_plain_invocation_self_launches(gpu):
+    """`python3 bench.py --gpus 2 ...` exactly as a driver types it -- NO launcher, a clean environment (no RANK /
+    WORLD_SIZE / MASTER_*): bench.py re-executes itself under torch.distributed.run, one rank per band, and prints ONE
+    JSON line with the single-image legs and the product's own route next to `value`."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+           "--size", "1024", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT), env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2 and d["warmup"] == 1
+    assert d["verify_band_edges_ok"] is True and d["verify_ok"] is True
+    assert d["value_batch1"] > 0 and d["single_plane_ms"] > 0
+    assert d["product_route"].get("error") is None and d["product_route"]["verify_ok"] is True
+    assert d["config"]["rccl_ranks"] == 0            # gloo on one device; RCCL runs report rccl_ranks == n_gpus
+
+
+def test_bench_self_launch_command_line(monkeypatch):
+    """CPU: the command bench.py replaces itself with for --gpus N (no launcher in the environment)"""
+    import bench
+    seen = {}
+
+    def fake_execve(exe, argv, env):
+        seen.update(exe=exe, argv=argv, env=env)
+        raise SystemExit(0)
+    monkeypatch.setattr(bench.os, "execve", fake_execve)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit):
+        bench.main()
+    a = seen["argv"]
+    assert a[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in a
+    assert a[a.index("--nproc-per-node") + 1] == "4" and a[a.index("--master-addr") + 1] == "127.0.0.1"
+    assert a[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and a[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher (WORLD_SIZE / RANK set) and for --gpus 1 it must NOT re-launch
+    import argparse
+    assert bench._needs_self_launch(argparse.Namespace(gpus=4), {}) is True
+    assert bench._needs_self_launch(argparse.Namespace(gpus=4), {"WORLD_SIZE": "4"}) is False
+    assert bench._needs_self_launch(argparse.Namespace(gpus=4), {"RANK": "0"}) is False
+    assert bench._needs_self_launch(argparse.Namespace(gpus=1), {}) is False
 
 
 @pytest.mark.gpu
