@@ -19,15 +19,16 @@
 // difference is one v_sub_f32; the 32 neighbour-edge pixels stay packed four to
 // a VGPR; the 64 int16 coefficients live in LDS, one dword column per lane
 // (stride 65 dwords => conflict-free both for the per-lane column accesses and
-// for the coalesced-load transpose).  147 VGPRs => 3 waves per SIMD.
+// for the coalesced-load transpose).  128 VGPRs => 4 waves per SIMD.
 //
-// This translation unit holds the SHIPPED kernels only.  The variants that were built and
-// measured on the way (and lost) are kept, compilable, under csrc/experiments/ and are
-// built only by tools/build_variants.sh; DESIGN.md has the numbers.
+// Build-time switches (all default to the measured-best setting; the others are
+// kept as checked-in experiments): QS_SMOOTH_MIN_WAVES,
+// QS_PIN_DIFFS, QS_PIN_EDGE, QS_SKIP_ZERO_WEIGHTS, QS_SMEM_PIPELINE,
+// QS_IDCT_DOT2, QS_ABLATE_*.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include "qs_device.h"
+#include "../qs_device.h"
 
 #define QS_LDS_PITCH 65 /* dwords per coefficient-pair row, 64 lanes + 1 pad */
 
@@ -61,6 +62,9 @@ __device__ __forceinline__ uint32_t lshl13_add(uint32_t x, uint32_t b) {
 // `bias` (the rounding constant of the descale that follows, plus the level shift
 // in pass 2) enters through the two DC terms, from where it reaches all eight
 // outputs exactly once: two adds instead of eight (integer ring arithmetic).
+#ifndef QS_IDCT_FOLD_BIAS
+#define QS_IDCT_FOLD_BIAS 1
+#endif
 __device__ __forceinline__ void idct8(uint32_t (&v)[8], uint32_t bias) {
   uint32_t z1, z2, z3, z4, z5, t0, t1, t2, t3, e0, e1, e2, e3;
   z2 = v[2]; z3 = v[6];
@@ -99,16 +103,26 @@ __device__ __forceinline__ void idct_pass1(uint32_t (&ws)[64]) {
     uint32_t col[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) col[j] = ws[j * 8 + x];
+#if QS_IDCT_FOLD_BIAS
     idct8(col, 1024u);
 #pragma unroll
     for (int j = 0; j < 8; ++j) ws[j * 8 + x] = (uint32_t)((int32_t)col[j] >> 11);
+#else
+    idct8(col, 0u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ws[j * 8 + x] = (uint32_t)((int32_t)(col[j] + 1024u) >> 11);
+#endif
   }
 }
 
 // pass 2 for one row; folds +128 and rounding, clamps to 0..255
 // (reference idct.h:509-538).
 __device__ __forceinline__ void idct_pass2_row(uint32_t (&row)[8], int (&out)[8]) {
+#if QS_IDCT_FOLD_BIAS
   idct8(row, 257u << 17);
+#else
+  idct8(row, 0u);
+#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     // clamp BEFORE the shift (same result as clamping (x >> 18) to 0..255).
@@ -117,7 +131,11 @@ __device__ __forceinline__ void idct_pass2_row(uint32_t (&row)[8], int (&out)[8]
     // bytes into bits 31:16 of its result as if they were zero -- they are
     // not on MI355X (observed: corrupted pixels 6/7 of every row).  Clamping
     // first keeps that instruction out; csrc/Makefile greps the ISA for it.
+#if QS_IDCT_FOLD_BIAS
     int z = (int32_t)row[j];
+#else
+    int z = (int32_t)(row[j] + (257u << 17));
+#endif
     z = min(max(z, 0), (256 << 18) - 1);
     out[j] = z >> 18;
   }
@@ -129,21 +147,90 @@ __device__ __forceinline__ void idct_pass2_row(uint32_t (&row)[8], int (&out)[8]
 // two such floats are exact and equal (pa - pb) * 2^-12, what the scaled term
 // arithmetic expects, and building one costs a single v_alignbit_b32 on the
 // clamped pass-2 value (or one SDWA v_or on a packed neighbour byte) instead
-// of shift + convert + multiply.
+// of shift + convert + multiply.  QS_PIX_MAGIC=0 keeps the plain p * 2^-12 form.
+#ifndef QS_PIX_MAGIC
+#define QS_PIX_MAGIC 1
+#endif
 #define QS_PIX_BITS 0x45000000u
 __device__ __forceinline__ void idct_pass2_row_f(uint32_t (&row)[8], float (&out)[8]) {
+#if QS_PIX_MAGIC
+#if QS_IDCT_FOLD_BIAS
   idct8(row, 257u << 17);
+#else
+  idct8(row, 0u);
+#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
+#if QS_IDCT_FOLD_BIAS
     int z = (int32_t)row[j];
+#else
+    int z = (int32_t)(row[j] + (257u << 17));
+#endif
     z = min(max(z, 0), (256 << 18) - 1);
     // {0x11400 : z} >> 18  =  (0x11400 << 14) | (z >> 18)  =  0x45000000 | pixel
     out[j] = __builtin_bit_cast(float, __builtin_amdgcn_alignbit(QS_PIX_BITS >> 14, (uint32_t)z, 18));
   }
+#else
+  int o[8];
+  idct_pass2_row(row, o);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = (float)o[j] * 0.000244140625f;
+#endif
 }
 // byte n of a packed word of neighbour pixels, in the same representation
 __device__ __forceinline__ float pix_from_byte(uint32_t v, int n) {
+#if QS_PIX_MAGIC
   return __builtin_bit_cast(float, QS_PIX_BITS | ((v >> (8 * n)) & 0xffu));
+#else
+  return (float)((v >> (8 * n)) & 0xffu) * 0.000244140625f;
+#endif
+}
+
+// --------------------------------------------------------------------------
+// QS_IDCT_DOT2: column pass of the refresh IDCT on packed int16 pairs.
+// In the recovery kernel the 64 coefficients of a block sit in LDS as 32
+// dwords.  With this option dword m = 4*x + t of a lane's column holds, for
+// block column x, the pair  t=0: (c0,c4)  t=1: (c2,c6)  t=2: (c7,c5)  t=3: (c3,c1)
+// (first = low half; cN = coefficient in row N), which is what the LL&M
+// butterfly consumes together: every partial sum of the column pass is a
+// 2-term dot product with constant int16 weights -> v_dot2c_i32_i16, one
+// instruction for two multiplies and two adds (the odd part is expanded into
+// its 4x4 integer matrix).  Integer ring arithmetic, so the regrouping is exact
+// (no overflow either: |coef| <= 3071 inside the recovery loop).
+// Measured on MI355X (A/B in one run, 4096^2): bit-exact, but not faster --
+// q3 0.541 vs 0.537 ms, q4 0.818 vs 0.793 ms: v_dot2c_i32_i16 issues at the
+// same half rate as v_mul_i32_i24 (tools/ubench_valu.hip) and the accumulator
+// v_movs plus the extra register pressure eat the saved adds.  Off by default;
+// kept as a checked-in negative result.
+#ifndef QS_IDCT_DOT2
+#define QS_IDCT_DOT2 0
+#endif
+typedef short qs_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2(uint32_t pair, int klo, int khi, int acc) {
+  const qs_s2 k = {(short)klo, (short)khi};
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(qs_s2, pair), k, acc, false);
+}
+// row of a coefficient -> (pair slot t, half h) of the layout above
+__device__ __forceinline__ constexpr int pair_slot(int r) { return r == 0 || r == 4 ? 0 : r == 2 || r == 6 ? 1 : r == 7 || r == 5 ? 2 : 3; }
+__device__ __forceinline__ constexpr int pair_half(int r) { return (r == 4 || r == 6 || r == 5 || r == 1) ? 1 : 0; }
+
+// one column: four packed pairs in, eight workspace values out (descaled by 11
+// with the rounding bias folded into the accumulators)
+__device__ __forceinline__ void idct_col_dot2(uint32_t p04, uint32_t p26, uint32_t p75, uint32_t p31, uint32_t (&o)[8]) {
+  const int t0 = dot2(p04, 8192, 8192, 1024);      // (c0 + c4) << 13, + rounding
+  const int t1 = dot2(p04, 8192, -8192, 1024);     // (c0 - c4) << 13, + rounding
+  const int t2 = dot2(p26, 4433, -10704, 0);       // z1 - c6 * 15137
+  const int t3 = dot2(p26, 10703, 4433, 0);        // z1 + c2 * 6270
+  const int e0 = t0 + t3, e3 = t0 - t3, e1 = t1 + t2, e2 = t1 - t2;
+  // odd part as a 4x4 integer matrix on (c7, c5, c3, c1)
+  const int q0 = dot2(p31, -6436, 2260, dot2(p75, -11363, 9633, 0));
+  const int q1 = dot2(p31, -11362, 6437, dot2(p75, 9633, 2261, 0));
+  const int q2 = dot2(p31, -2259, 9633, dot2(p75, -6436, -11362, 0));
+  const int q3 = dot2(p31, 9633, 11363, dot2(p75, 2260, 6437, 0));
+  o[0] = (uint32_t)((e0 + q3) >> 11); o[7] = (uint32_t)((e0 - q3) >> 11);
+  o[1] = (uint32_t)((e1 + q2) >> 11); o[6] = (uint32_t)((e1 - q2) >> 11);
+  o[2] = (uint32_t)((e2 + q1) >> 11); o[5] = (uint32_t)((e2 - q1) >> 11);
+  o[3] = (uint32_t)((e3 + q0) >> 11); o[4] = (uint32_t)((e3 - q0) >> 11);
 }
 
 // --------------------------------------------------------------------------
@@ -231,7 +318,7 @@ qs_idct_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coe
   idct_block_to_plane(cst, coef, plane, wblk, hblk, pitch, first, rep_top, rep_bot, status, blk);
 }
 
-#include "qs_devfn.h"
+#include "../qs_devfn.h"
 
 // pass A over a set of planes (whole planes, or bands whose halo-side apron rows are left alone)
 __global__ void __launch_bounds__(256)
@@ -255,12 +342,24 @@ qs_idct_set_kernel(const QsPlaneSet set, int first) {
 // 32-bit accesses used for staging and for the IDCT refresh, and the compiler
 // must not reorder one kind across the other (it does under strict aliasing).
 typedef int16_t __attribute__((may_alias)) lds_i16;
+__device__ __forceinline__ int lds_halfword(int i) {   // index of coefficient i in 16-bit units, pitch aside
+#if QS_IDCT_DOT2
+  const int r = i >> 3, x = i & 7;
+  const int t = (0x21203130 >> (4 * r)) & 3;         // rows {0,4}->0 {2,6}->1 {7,5}->2 {3,1}->3
+  const int h = (0x72 >> r) & 1;                      // rows 1, 4, 5, 6 are the high half
+  return ((x * 4 + t) << 1) | h;
+#else
+  return i;
+#endif
+}
 __device__ __forceinline__ int lds_coef(const uint32_t* col, int i) {
-  const lds_i16* p = reinterpret_cast<const lds_i16*>(col + (i >> 1) * QS_LDS_PITCH) + (i & 1);
+  const int hw = lds_halfword(i);
+  const lds_i16* p = reinterpret_cast<const lds_i16*>(col + (hw >> 1) * QS_LDS_PITCH) + (hw & 1);
   return *p;
 }
 __device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
-  lds_i16* p = reinterpret_cast<lds_i16*>(col + (i >> 1) * QS_LDS_PITCH) + (i & 1);
+  const int hw = lds_halfword(i);
+  lds_i16* p = reinterpret_cast<lds_i16*>(col + (hw >> 1) * QS_LDS_PITCH) + (hw & 1);
   *p = (lds_i16)v;
 }
 
@@ -290,30 +389,182 @@ __device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
     den = den + y_ * y_; }
 #define QS_TERM(A, B, W) { float d_ = (A) - (B); QS_TERM_D(d_, W) }
 
-// Scalar operands of the coefficient walk are fetched by hand-placed scalar loads: the compiler does not know
-// about them, so every wait is tied to its buffer through a "+s" operand (uses cannot move above it).
-typedef float qs_w16 __attribute__((ext_vector_type(16)));     // one 16-weight chunk
-typedef int qs_i4 __attribute__((ext_vector_type(4)));         // one per-coefficient record (QsConsts::rec)
+#ifndef QS_PIN_DIFFS
+#define QS_PIN_DIFFS 1
+#endif
+// skip the difference terms whose weight is structurally zero (see QS_TERM_OPT)
+#ifndef QS_SKIP_ZERO_WEIGHTS
+#define QS_SKIP_ZERO_WEIGHTS 1
+#endif
+// QS_PIN_EDGE=1 recomputes the 32 edge-pixel conversions at every anti-diagonal
+// (no scratch: HBM traffic stays close to the algorithmic 256 B/block); 0 lets
+// the compiler hoist them out of the loop, where they end up in 124 B/lane of
+// scratch (+130 MB written and re-read per 8192^2 launch).  Measured A/B on
+// MI355X: 1 is 1 % faster at 8192^2 and 3 % slower at 4096^2 -- a wash in time,
+// so the variant without the spill traffic is the default.
+#ifndef QS_PIN_EDGE
+#define QS_PIN_EDGE 1
+#endif
+// Explicit double-buffered scalar weight prefetch (QS_STEP below), used by the
+// low-occupancy kernel variant.  Measured on MI355X: with 4 waves per SIMD in
+// flight the compiler's own s_load placement is covered by the other waves and
+// is a few % faster; with 1-2 waves per SIMD (planes below ~190k blocks, e.g. a
+// 1/8 band of an 8192^2 image) the explicit pipeline is 25-75 % faster.
+typedef float qs_w16 __attribute__((ext_vector_type(16)));
+// explicit scalar loads: the compiler does not know about them, so the wait is
+// tied to the buffer through a "+s" operand (uses cannot move above it)
+#define QS_SLOAD16(BUF, BYTEOFF) \
+  asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(BUF) : "s"(tabp), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)(BYTEOFF))) : "memory")
 #define QS_SWAIT(BUF) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(BUF) : : "memory")
+// One pipeline step: wait for the chunk in CUR, then immediately issue the load
+// of the following chunk into NXT.  The num/den operands pin the step between
+// the accumulations of the previous chunk and those of this one -- without
+// them the scheduler hoists/sinks the surrounding VALU work across the asm and
+// the load ends up right in front of its own wait.
+#define QS_STEP(CUR, NXT, BYTEOFF) \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %1, %4, %5" \
+               : "+s"(CUR), "=&s"(NXT), "+v"(num), "+v"(den) \
+               : "s"(tabp), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)(BYTEOFF))) : "memory")
+
+// QS_REC_PREFETCH=1 (default): the per-coefficient scalars come from QsConsts::rec through ONE
+// explicit scalar load at the top of the coefficient; 0 = left to the compiler, which fetches them
+// with five global_load_dword + v_readfirstlane (kept for A/B runs)
+#ifndef QS_REC_PREFETCH
+#define QS_REC_PREFETCH 1
+#endif
+// QS_LAND_PIPELINE=1: chunk steps wait at their END for the load they issued at their start
+// (nothing in flight across statements other than one straight-line run of terms), and the
+// record of the next coefficient rides on the last step; 0 = wait at the start of the next step
+#ifndef QS_LAND_PIPELINE
+#define QS_LAND_PIPELINE 1
+#endif
+// per-coefficient record (QsConsts::rec), same discipline: issued right behind a weight-chunk
+// load, complete after the next s_waitcnt lgkmcnt(0)
+typedef int qs_i4 __attribute__((ext_vector_type(4)));
+#define QS_SLOAD4(BUF, BYTEOFF) \
+  asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(BUF) : "s"(recp), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)(BYTEOFF))) : "memory")
+__device__ __forceinline__ float byte_f(uint32_t v, int n) { return (float)((v >> (8 * n)) & 0xffu); }
 
 // waves per workgroup: the waves of a workgroup share nothing (each has its own
 // LDS slice), so the size only sets the dispatch granularity
+#ifndef QS_WAVES_PER_WG
 #define QS_WAVES_PER_WG 4
-// register budget: 3 waves per SIMD (168 VGPRs; the kernel uses 147).  Measured: 2 waves per SIMD -11 %, a
-// 4-wave budget (128 VGPRs, edge differences recomputed per term) -7.5 %.
-#define QS_SMOOTH_MIN_WAVES 3
-// workgroups the chip holds at once = 256 CUs x 3 (a workgroup puts one wave on each of a CU's four SIMDs):
-// the tail-round rule of qs_smooth_kernel.inc
-#define QS_RESIDENT_WG (256 * QS_SMOOTH_MIN_WAVES * 4 / QS_WAVES_PER_WG)
-// wave priority of the slow phases (refresh IDCT, coefficient update) and of the term streams, see
-// qs_smooth_kernel.inc.  Any raised level works alike (1 / 2 / 3 measured equal); the OPPOSITE assignment is 5 %
-// slower than no priorities at all.
-#define QS_PRIO_SLOW 3
-#define QS_PRIO_TERMS 0
+#endif
 
-// One term with a structurally-zero weight for some frequencies (small-plane kernel): the nine instructions carry
-// their own wave-uniform scalar test and branch, so the compiler sees straight-line code (branching in C++ made
-// hipcc spill 240-430 B/lane and run 1.7x slower).
+// QS_FUSE_REBALANCE_SUMS: collect the rebalance step's two sums while the coefficients are
+// updated (see qs_smooth_kernel.inc); 0 = separate pass over the block afterwards
+#ifndef QS_FUSE_REBALANCE_SUMS
+#define QS_FUSE_REBALANCE_SUMS 1
+#endif
+// QS_EDGE_INLINE=1: no register-resident edge differences (see qs_smooth_kernel.inc): with
+// QS_SMOOTH_MIN_WAVES=4 the kernel fits 128 VGPRs = four waves per SIMD
+#ifndef QS_EDGE_INLINE
+#define QS_EDGE_INLINE 0
+#endif
+#ifndef QS_SMOOTH_OCCUPANCY       /* waves per SIMD the default kernel actually gets (tail-round rule) */
+#define QS_SMOOTH_OCCUPANCY 3
+#endif
+// tail-round wave priority (see qs_smooth_kernel.inc); workgroups the chip holds at
+// once = 256 CUs x 3 (the kernel's VGPR budget leaves room for 3 waves per SIMD and a
+// workgroup puts one wave on each of a CU's four SIMDs)
+// QS_REFRESH_SKIP=1: the refresh IDCT at an anti-diagonal start is skipped when no block of the
+// wave changed a coefficient since the previous refresh (the reference's need_refresh,
+// quantsmooth.h:1407-1409, made wave-uniform); exact by construction.
+#ifndef QS_REFRESH_SKIP
+#define QS_REFRESH_SKIP 1
+#endif
+// the nine instructions of one term as a string, operands by name (for multi-term asm blocks)
+#define QS_TSTR(A, B, W) \
+          "v_sub_f32 %[d], %[" #A "], %[" #B "]\n\t" \
+          "v_sub_f32 %[t], %[r], |%[d]| clamp\n\t" \
+          "v_mul_f32 %[t], %[t], %[t]\n\t" \
+          "v_mul_f32 %[d], %[d], %[t]\n\t" \
+          "v_mul_f32 %[t], %[" #W "], %[t]\n\t" \
+          "v_mul_f32 %[d], %[d], %[t]\n\t" \
+          "v_add_f32 %[n], %[n], %[d]\n\t" \
+          "v_mul_f32 %[d], %[t], %[t]\n\t" \
+          "v_add_f32 %[e], %[e], %[d]\n\t"
+// one pixel row's seven horizontal differences (MODE 0), without x = 3 (MODE 1), without x = 1, 3, 5 (MODE 2)
+#define QS_HROW_TERMS_0 QS_TSTR(p0, p1, w0) QS_TSTR(p1, p2, w1) QS_TSTR(p2, p3, w2) QS_TSTR(p3, p4, w3) QS_TSTR(p4, p5, w4) QS_TSTR(p5, p6, w5) QS_TSTR(p6, p7, w6)
+#define QS_HROW_TERMS_1 QS_TSTR(p0, p1, w0) QS_TSTR(p1, p2, w1) QS_TSTR(p2, p3, w2) QS_TSTR(p4, p5, w4) QS_TSTR(p5, p6, w5) QS_TSTR(p6, p7, w6)
+#define QS_HROW_TERMS_2 QS_TSTR(p0, p1, w0) QS_TSTR(p2, p3, w2) QS_TSTR(p4, p5, w4) QS_TSTR(p6, p7, w6)
+#define QS_HROW_ASM(P, W, WO, MODE) { float d_, t_; \
+        asm volatile(QS_HROW_TERMS_##MODE \
+          : [n] "+v"(num), [e] "+v"(den), [d] "=&v"(d_), [t] "=&v"(t_) \
+          : [p0] "v"((P)[0]), [p1] "v"((P)[1]), [p2] "v"((P)[2]), [p3] "v"((P)[3]), [p4] "v"((P)[4]), [p5] "v"((P)[5]), \
+            [p6] "v"((P)[6]), [p7] "v"((P)[7]), [w0] "s"(W[(WO) + 0]), [w1] "s"(W[(WO) + 1]), [w2] "s"(W[(WO) + 2]), \
+            [w3] "s"(W[(WO) + 3]), [w4] "s"(W[(WO) + 4]), [w5] "s"(W[(WO) + 5]), [w6] "s"(W[(WO) + 6]), [r] "s"(Rs)); }
+// one row of eight vertical differences: row P against row Q (the next pixel row)
+#define QS_VROW_ASM(P, Q, W, WO) { float d_, t_; \
+        asm volatile(QS_TSTR(p0, q0, w0) QS_TSTR(p1, q1, w1) QS_TSTR(p2, q2, w2) QS_TSTR(p3, q3, w3) \
+                     QS_TSTR(p4, q4, w4) QS_TSTR(p5, q5, w5) QS_TSTR(p6, q6, w6) QS_TSTR(p7, q7, w7) \
+          : [n] "+v"(num), [e] "+v"(den), [d] "=&v"(d_), [t] "=&v"(t_) \
+          : [p0] "v"((P)[0]), [p1] "v"((P)[1]), [p2] "v"((P)[2]), [p3] "v"((P)[3]), [p4] "v"((P)[4]), [p5] "v"((P)[5]), \
+            [p6] "v"((P)[6]), [p7] "v"((P)[7]), [q0] "v"((Q)[0]), [q1] "v"((Q)[1]), [q2] "v"((Q)[2]), [q3] "v"((Q)[3]), \
+            [q4] "v"((Q)[4]), [q5] "v"((Q)[5]), [q6] "v"((Q)[6]), [q7] "v"((Q)[7]), \
+            [w0] "s"(W[(WO) + 0]), [w1] "s"(W[(WO) + 1]), [w2] "s"(W[(WO) + 2]), [w3] "s"(W[(WO) + 3]), \
+            [w4] "s"(W[(WO) + 4]), [w5] "s"(W[(WO) + 5]), [w6] "s"(W[(WO) + 6]), [w7] "s"(W[(WO) + 7]), [r] "s"(Rs)); }
+// QS_PHASE_PRIO=1: a wave runs the slow phases of the coefficient walk -- the refresh IDCT (integer butterflies, a third
+// of them half-rate multiplies) and the coefficient update (division, interval, LDS read-modify-write) -- at RAISED wave
+// priority (s_setprio) and its term streams at the base priority.  With three waves per SIMD the pipe idles when two of
+// them are in a slow phase at once and the third cannot fill it alone (tools/timeline.py); at raised priority a wave leaves
+// its slow phase as fast as the hardware allows and such overlaps become rare.  QS_PRIO_REFRESH / _UPDATE / _TERMS: the levels.
+// Measured (profiles/r03l_phase_prio, one session, 20 steps each): q3 226.8 -> 255.3 M blocks/s (+12.6 %), q4 144.8 -> 166.3
+// (+15 %); refresh only +10 %, update only +2 %; the levels do not matter (1 / 2 / 3 alike), the OPPOSITE assignment
+// (terms above the slow phases) is 5 % slower than no priorities at all.  Identical results (same hashes).
+#ifndef QS_PHASE_PRIO
+#define QS_PHASE_PRIO 1
+#endif
+#ifndef QS_PRIO_REFRESH
+#define QS_PRIO_REFRESH 3
+#endif
+#ifndef QS_PRIO_UPDATE
+#define QS_PRIO_UPDATE 3
+#endif
+#ifndef QS_PRIO_TERMS
+#define QS_PRIO_TERMS 0
+#endif
+// ... and the same in the diagonal-parallel (small-plane) kernel
+#ifndef QS_DP_PHASE_PRIO
+#define QS_DP_PHASE_PRIO 1
+#endif
+// QS_EARLY_C0=1: the coefficient's LDS read is issued before the division of its update step (latency hiding)
+#ifndef QS_EARLY_C0
+#define QS_EARLY_C0 1
+#endif
+// QS_TIMELINE=1 (measurement builds only, tools/timeline.py): every wave of qs_smooth_plane_kernel accumulates the
+// shader cycles (s_memtime) it spends in the three phases of the coefficient walk -- refresh IDCT, term stream,
+// coefficient update -- plus its staging prologue and its whole life, and lane 0 stores them into a device buffer
+// registered through qs_hip_debug_timeline().  Each stamp is a scalar-memory read with its own wait (~3 % perturbation).
+#ifndef QS_TIMELINE
+#define QS_TIMELINE 0
+#endif
+#if QS_TIMELINE
+__device__ unsigned long long* qs_tl_buf = nullptr;
+#define QS_TL_NOW(T) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T) : : "memory")
+extern "C" int qs_hip_debug_timeline(void* dev_buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(dev_buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(qs_tl_buf), &p, sizeof p) == hipSuccess ? 0 : -1;
+}
+#endif
+// QS_SECTION_SPEC=1: the zero-weight skip is decided once per horizontal / vertical section (three
+// specialised copies of the section) instead of by a scalar compare-and-branch in front of 48 terms
+// (=1, one opaque asm block per term: +0.7 % before the phase priorities of QS_PHASE_PRIO -- inside the noise --, +2.1 % with
+//  them, 258.0 against 252.5-253.0 M blocks/s, and 4-5 % for a lone wave per SIMD; =2, one asm block per pixel row: 7 % slower)
+#ifndef QS_SECTION_SPEC
+#define QS_SECTION_SPEC 1
+#endif
+#ifndef QS_TAIL_PRIO
+#define QS_TAIL_PRIO 1
+#endif
+#define QS_RESIDENT_WG (256 * QS_SMOOTH_OCCUPANCY * 4 / QS_WAVES_PER_WG)
+// measurement only: extra (unused) LDS dwords per wave, to cap how many workgroups a CU holds
+// without touching the code (occupancy experiments: 2400 -> 2 waves per SIMD), see DESIGN.md
+#ifndef QS_LDS_EXTRA
+#define QS_LDS_EXTRA 0
+#endif
+
+#if QS_SKIP_ZERO_WEIGHTS
 #define QS_TERM_OPT(COND, A, B, W) { float d_, t_; \
         asm volatile( \
           "s_cmp_lg_u32 %[c], 0\n\t" \
@@ -330,7 +581,11 @@ typedef int qs_i4 __attribute__((ext_vector_type(4)));         // one per-coeffi
           "1:" \
           : [n] "+v"(num), [e] "+v"(den), [d] "=&v"(d_), [t] "=&v"(t_) \
           : [a] "v"(A), [b] "v"(B), [w] "s"(W), [r] "s"(Rs), [c] "s"(COND) : "scc"); }
-// the same nine instructions as one opaque block (the section-specialised copies of qs_smooth_kernel.inc)
+#else
+#define QS_TERM_OPT(COND, A, B, W) QS_TERM(A, B, W)
+#endif
+// the same nine instructions as one opaque block (QS_SECTION_SPEC: the three specialised copies of a section must
+// not share subexpressions, or hipcc hoists ~100 pixel differences above the branch and spills them)
 #define QS_TERM_ASM(A, B, W) { float d_, t_; \
         asm volatile( \
           "v_sub_f32 %[d], %[a], %[b]\n\t" \
@@ -345,24 +600,52 @@ typedef int qs_i4 __attribute__((ext_vector_type(4)));         // one per-coeffi
           : [n] "+v"(num), [e] "+v"(den), [d] "=&v"(d_), [t] "=&v"(t_) \
           : [a] "v"(A), [b] "v"(B), [w] "s"(W), [r] "s"(Rs)); }
 
-// The recovery kernel (qs_smooth_kernel.inc): one plane, and a set of planes (job / batch layer: parameters come
-// from the plane set in the kernarg segment instead of from scalar arguments)
+// Two instantiations of the kernel body (qs_smooth_kernel.inc):
+//   qs_smooth_plane_kernel      the default: scalar weights streamed through an
+//                               explicit double buffer (QS_STEP), 168 VGPRs, no scratch;
+//                               does not depend on other waves to hide latency
+//   qs_smooth_plane_kernel_alt  weight loads left to the compiler, 128 VGPRs (4 waves
+//                               per SIMD); kept for A/B runs (QS_FORCE_VARIANT=0)
 #define QS_SMOOTH_KERNEL_NAME qs_smooth_plane_kernel
-#include "qs_smooth_kernel.inc"
+#define QS_SMEM_PIPELINE 1
+#ifndef QS_SMOOTH_MIN_WAVES
+#define QS_SMOOTH_MIN_WAVES 3
+#endif
+#include "qs_smooth_kernel_r03.inc"
 #undef QS_SMOOTH_KERNEL_NAME
+#undef QS_SMEM_PIPELINE
+#undef QS_SMOOTH_MIN_WAVES
+
+// the same kernel over a set of planes (job / batch layer): parameters come
+// from the plane set in the kernarg segment instead of from scalar arguments
 #define QS_SMOOTH_KERNEL_NAME qs_smooth_set_kernel
+#define QS_SMEM_PIPELINE 1
+#define QS_SMOOTH_MIN_WAVES 3
 #define QS_SMOOTH_SET 1
-#include "qs_smooth_kernel.inc"
+#include "qs_smooth_kernel_r03.inc"
 #undef QS_SMOOTH_KERNEL_NAME
+#undef QS_SMEM_PIPELINE
+#undef QS_SMOOTH_MIN_WAVES
 #undef QS_SMOOTH_SET
 
+#define QS_SMOOTH_KERNEL_NAME qs_smooth_plane_kernel_alt
+#define QS_SMEM_PIPELINE 0
+#define QS_SMOOTH_MIN_WAVES 4
+#include "qs_smooth_kernel_r03.inc"
+#undef QS_SMOOTH_KERNEL_NAME
+#undef QS_SMEM_PIPELINE
+#undef QS_SMOOTH_MIN_WAVES
+
 // Small planes: the diagonal-parallel form of the same pass (qs_smooth_dp_kernel.inc)
+#ifndef QS_DP_SHARED_REFRESH
+#define QS_DP_SHARED_REFRESH 1
+#endif
 #define QS_DP_KERNEL_NAME qs_smooth_dp_kernel
-#include "qs_smooth_dp_kernel.inc"
+#include "qs_smooth_dp_kernel_r03.inc"
 #undef QS_DP_KERNEL_NAME
 #define QS_DP_KERNEL_NAME qs_smooth_dp_set_kernel
 #define QS_DP_SET 1
-#include "qs_smooth_dp_kernel.inc"
+#include "qs_smooth_dp_kernel_r03.inc"
 #undef QS_DP_KERNEL_NAME
 #undef QS_DP_SET
 
@@ -410,7 +693,7 @@ qs_dequant_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef, 
 
 // --------------------------------------------------------------------------
 // launchers (C++ linkage, used by qs_planes.cpp and qs_job.cpp through qs_launch.h)
-#include "qs_launch.h"
+#include "../qs_launch.h"
 
 void qs_launch_idct_plane(const QsConsts* cst, int16_t* coef, uint8_t* plane, int wblk, int hblk,
                           int first, int rep_top, int rep_bot, int* status, hipStream_t s) {
@@ -459,9 +742,19 @@ void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* p
   }
   const int per_wg = 64 * QS_WAVES_PER_WG;
   const dim3 grid((n + per_wg - 1) / per_wg), block(per_wg);
+  // The pipelined kernel is the default at every size: measured A/B on MI355X it
+  // is 40-60 % faster than the compiler-scheduled one on planes that leave SIMDs
+  // with 1-2 waves (1448^2 .. 2880^2, i.e. also a 1/8 band of 8192^2) and 0-2 %
+  // faster on 4096^2 .. 8192^2.  QS_FORCE_VARIANT=0 selects the other for A/B runs.
+#ifdef QS_FORCE_VARIANT
+  const bool alt = QS_FORCE_VARIANT == 0;
+#else
+  const bool alt = false;
+#endif
   const int pitch = qs_plane_pitch(wblk);
 #define QS_GO(K) hipLaunchKernelGGL(K, grid, block, 0, s, cst, coef, plane, wblk, hblk, pitch, rebalance, final_clamp, blk_begin, blk_end)
-  if (diag) QS_GO(qs_smooth_plane_kernel<true>); else QS_GO(qs_smooth_plane_kernel<false>);
+  if (alt) { if (diag) QS_GO(qs_smooth_plane_kernel_alt<true>); else QS_GO(qs_smooth_plane_kernel_alt<false>); }
+  else     { if (diag) QS_GO(qs_smooth_plane_kernel<true>);     else QS_GO(qs_smooth_plane_kernel<false>); }
 #undef QS_GO
 }
 

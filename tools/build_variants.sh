@@ -1,6 +1,8 @@
 #!/bin/bash
 # Build tuning variants of libjpegqs_hip.so into build/variants/ (measurement only).
 #   tools/build_variants.sh "name1:-DFLAG=1 -DX=2" "name2:..."
+# A spec "name:..." is built from the SHIPPED kernel source (csrc/qs_kernels.hip) when its flags start with "@ship",
+# otherwise from the round-3 experiments source with all of its QS_* switches (csrc/experiments/qs_kernels_r03.hip).
 set -e
 cd "$(dirname "$0")/../jpeg-quantsmooth_amd/csrc"
 OUT=../../build/variants; rm -rf $OUT; mkdir -p $OUT
@@ -9,7 +11,9 @@ for f in qs_tables qs_planes qs_job qs_fused qs_batch qs_shard; do hipcc $HIPFLA
 hipcc $HIPFLAGS -c qs_kernels_aux.hip -o $OUT/qs_aux.o
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
-  hipcc $HIPFLAGS $flags -c qs_kernels.hip -o $OUT/k_$name.o
+  src=experiments/qs_kernels_r03.hip
+  case "$flags" in "@ship"*) src=qs_kernels.hip; flags=${flags#@ship} ;; esac
+  hipcc $HIPFLAGS -I. $flags -c $src -o $OUT/k_$name.o
   hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libjpegqs_hip_$name.so $OUT/k_$name.o $OUT/qs_aux.o $OUT/qs_tables.o $OUT/qs_planes.o $OUT/qs_job.o $OUT/qs_fused.o $OUT/qs_batch.o $OUT/qs_shard.o
 done
 rm -f $OUT/*.o; ls $OUT
