@@ -550,8 +550,10 @@ def run_luma(c):
     work = [[pristine.clone() for _ in range(batch)] for _ in range(nsteps)]   # resident inputs, one set per step
     # the pixel planes of the batch live in one [batch, plane_bytes] tensor: the halo rows of all of them
     # are then packed / unpacked with one strided copy each (bands.exchange_halo_packed)
+    # (two of them: pass B writes the next iteration's pixel planes into the other one, fused pass A)
     planes2d = torch.zeros((batch, (hip.plane_bytes(wblk, hblk) + 255) & ~255), dtype=torch.uint8, device=dev)
-    eng = bands.HipBandEngine(hip, torch, work[0][0], quant, flags, luma=1, device=dev, plane=planes2d[0])
+    planes2d_b = torch.zeros_like(planes2d)
+    eng = bands.HipBandEngine(hip, torch, work[0][0], quant, flags, luma=1, device=dev, plane=planes2d[0], plane2=planes2d_b[0])
     stream = torch.cuda.current_stream()
     ev_pairs = []
     is_band = topo.up is not None or topo.down is not None
@@ -561,11 +563,13 @@ def run_luma(c):
     # per pass for all of them (a lone 1/8 band leaves the chip two-thirds idle; at N = 1 it saves the
     # twelve launch tails) and, for N > 1, ONE batched halo exchange per iteration (latency-bound: 2 rows
     # of 8 KB per plane).  --overlap keeps the older per-plane schedule.
-    engs = [eng] + [bands.HipBandEngine(hip, torch, work[0][b], quant, flags, luma=1, device=dev, plane=planes2d[b])
+    engs = [eng] + [bands.HipBandEngine(hip, torch, work[0][b], quant, flags, luma=1, device=dev, plane=planes2d[b], plane2=planes2d_b[b])
                     for b in range(1, batch)] if not args.overlap else None
 
     def exch_many(part, lo):
-        bands.exchange_halo_packed(hip, planes2d[lo:lo + len(part)], wblk, hblk, topo, dist, hostcopy=args.backend != "nccl")
+        # the planes the coming pass B reads: whichever of the two tensors the engines' `plane` points into right now
+        cur = planes2d if part[0].plane.data_ptr() == planes2d[lo].data_ptr() else planes2d_b
+        bands.exchange_halo_packed(hip, cur[lo:lo + len(part)], wblk, hblk, topo, dist, hostcopy=args.backend != "nccl")
     pending = []
 
     def mark(which):

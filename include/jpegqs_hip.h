@@ -176,6 +176,12 @@ int qs_hip_idct_plane(const void *d_consts, int16_t *d_coef, uint8_t *d_plane,
  * Supported here: flags & (DIAGONALS | NO_REBALANCE | NO_REBALANCE_UV). */
 int qs_hip_smooth_plane(const void *d_consts, int16_t *d_coef, const uint8_t *d_plane,
 		int wblk, int hblk, int flags, int luma, int final_clamp, void *stream);
+/* pass B that ALSO writes the pixel plane of the next iteration (pass A of iteration n + 1 fused into pass B of
+ * iteration n: the kernel holds the block's final coefficients anyway).  d_plane_next must be a second plane of the
+ * same geometry -- the other blocks of the launch still read d_plane -- and receives exactly what
+ * qs_hip_idct_plane(first = 0, rep_top, rep_bot) would write after this call.  Reference :2589-2620 + :2627-2640. */
+int qs_hip_smooth_plane_next(const void *d_consts, int16_t *d_coef, const uint8_t *d_plane, uint8_t *d_plane_next,
+		int wblk, int hblk, int flags, int luma, int final_clamp, int rep_top, int rep_bot, void *stream);
 /* the same for block rows [row0, row1) only: a band runs its interior rows while
  * the halo rows are still in flight and its first/last row afterwards */
 int qs_hip_smooth_rows(const void *d_consts, int16_t *d_coef, const uint8_t *d_plane,
@@ -193,6 +199,8 @@ typedef struct {
 	int32_t wblk, hblk, luma;
 	int32_t band;  /* 0: a whole plane.  Bit 0 / bit 1: the plane is a band of block rows whose top /
 	                * bottom apron row is a halo row received from the neighbouring band (pass A leaves it alone) */
+	uint8_t *d_plane_next;  /* qs_hip_smooth_planes: NULL, or the second plane the next iteration's pixels go to
+	                         * (see qs_hip_smooth_plane_next); ignored by qs_hip_idct_planes */
 } qs_hip_plane_ref;
 int qs_hip_idct_planes(const qs_hip_plane_ref *refs, int n, int first, void *stream);
 int qs_hip_smooth_planes(const qs_hip_plane_ref *refs, int n, int flags, int final_clamp, void *stream);

@@ -228,24 +228,39 @@ def run_bands_batched(engines, topo: BandTopology, niter: int, exchange_many) ->
             e.smooth(it == niter - 1)
 
 
-def run_bands_batched_sets(hip, engines, topo: BandTopology, niter: int, exchange_many, stream=None, mark=None) -> None:
+def run_bands_batched_sets(hip, engines, topo: BandTopology, niter: int, exchange_many, stream=None, mark=None, fused=True) -> None:
     """run_bands_batched with ONE launch per pass for all planes of the batch (plane sets,
     qs_hip_idct_planes / qs_hip_smooth_planes): a 1/8 band of an 8192^2 plane is 2048 waves, two per
     SIMD -- launched alone it runs at 72 % of the rate the same kernel reaches once the chip is full
-    (DESIGN.md 4.2b table); twelve bands in one launch fill it.  HipBandEngine objects only."""
+    (DESIGN.md 4.2b table); twelve bands in one launch fill it.  HipBandEngine objects only.
+
+    fused (default): pass A runs ONCE; every pass B but the last writes the next iteration's pixel planes itself
+    (qs_hip_plane_ref::d_plane_next) into each engine's second plane, and the engines' `plane` / `plane2` swap --
+    `engine.plane` (and `engine.row()`) is always the plane the coming pass B reads, which is what
+    `exchange_many()` must exchange the halo rows of.  Per iteration: [halo rows], ONE launch."""
     band = (1 if topo.up is not None else 0) | (2 if topo.down is not None else 0)
     flags = engines[0].flags
     s = stream if stream is not None else engines[0]._s()
+    if fused:
+        for e in engines:
+            e.ensure_plane2()
     for it in range(niter):
-        refs = hip.plane_refs([(e.cst.data_ptr(), e.coef.data_ptr(), e.plane.data_ptr(), e.status.data_ptr(),
-                                e.wblk, e.hblk, e.luma, band) for e in engines])
-        hip.idct_planes(refs, it == 0, s)
+        if it == 0 or not fused:
+            refs = hip.plane_refs([(e.cst.data_ptr(), e.coef.data_ptr(), e.plane.data_ptr(), e.status.data_ptr(),
+                                    e.wblk, e.hblk, e.luma, band) for e in engines])
+            hip.idct_planes(refs, it == 0, s)
         exchange_many()
+        nxt = fused and it < niter - 1
+        refs = hip.plane_refs([(e.cst.data_ptr(), e.coef.data_ptr(), e.plane.data_ptr(), e.status.data_ptr(),
+                                e.wblk, e.hblk, e.luma, band, e.plane2.data_ptr() if nxt else None) for e in engines])
         if mark:
             mark(0)                                  # (bench.py: HIP events around the pass-B launch)
         hip.smooth_planes(refs, flags, it == niter - 1, s)
         if mark:
             mark(1)
+        if nxt:
+            for e in engines:
+                e.plane, e.plane2 = e.plane2, e.plane
 
 
 def exchange_halo_local(engines) -> None:
@@ -303,7 +318,7 @@ def run_band_overlapped(engine: BandEngine, topo: BandTopology, niter: int, exch
 class HipBandEngine(BandEngine):
     """band backend on the MI355X kernels; all buffers are torch device tensors"""
 
-    def __init__(self, hip, torch, coef, quant, flags, luma=1, device=None, stream=None, plane=None):
+    def __init__(self, hip, torch, coef, quant, flags, luma=1, device=None, stream=None, plane=None, plane2=None):
         self.hip, self.torch = hip, torch
         self.coef = coef                                   # int16 [hblk, wblk, 64] on device
         self.hblk, self.wblk = int(coef.shape[0]), int(coef.shape[1])
@@ -314,9 +329,16 @@ class HipBandEngine(BandEngine):
         # that the halo rows of a whole batch can be packed with one strided copy: exchange_halo_packed)
         self.plane = plane if plane is not None else \
             torch.zeros(hip.plane_bytes(self.wblk, self.hblk), dtype=torch.uint8, device=dev)
+        # the second plane of the fused schedule (run_bands_batched_sets): pass B writes the next iteration's pixels
+        # there; allocated on first use unless the caller owns it (as for `plane`)
+        self.plane2 = plane2
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.pitch = hip.plane_pitch(self.wblk)
         self._stream = stream
+
+    def ensure_plane2(self):
+        if self.plane2 is None:
+            self.plane2 = self.torch.zeros_like(self.plane)
 
     def _s(self):
         s = self._stream if self._stream is not None else self.torch.cuda.current_stream()

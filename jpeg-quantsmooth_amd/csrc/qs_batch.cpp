@@ -2,6 +2,7 @@
 // callers that serve many images, FROZEN since round 2): whole jobs spread over the configured devices,
 // independent-component jobs as plane-set groups (qs_fused.cpp), coupled YCbCr jobs advancing in groups
 // (run_coupled below), everything else job by job.  (Split out of qs_job.cpp.)
+#include <functional>
 #include <list>
 #include <system_error>
 
@@ -63,6 +64,8 @@ struct ComputeSlot {
   ComputeSlot& operator=(const ComputeSlot&) = delete;
 };
 
+static size_t plane_stride(int wb, int hb) { return (qs_hip_plane_bytes(wb, hb) + 255) & ~(size_t)255; }
+
 static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, int flags, int niter, int* results) {
   StreamLease lease;
   if (!lease.p) return qs_fail(QS_HIP_ENODEV, "could not create HIP streams: %s", hipGetErrorString(hipGetLastError()));
@@ -88,7 +91,7 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
   DrainGuard drain{lease.p};                                // (after every buffer: the stream is drained first)
 
   // ---- layout.  Coefficients: [all luma][all chroma], so each class is clamped by one launch.
-  size_t coef_bytes = 0, px_bytes = 0, upx_bytes = 0, upc_bytes = 0, luma_blocks = 0, chroma_blocks = 0;
+  size_t coef_bytes = 0, px_bytes = 0, upx_bytes = 0, upc_bytes = 0;
   std::vector<const uint16_t*> qtabs;
   for (int pass = 0; pass < 2; ++pass)
     for (int g = 0; g < G; ++g) {
@@ -97,8 +100,7 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
       for (int ci = pass ? 1 : 0; ci < (pass ? 3 : 1); ++ci) {
         const size_t nb = (size_t)job->wblk[ci] * job->hblk[ci];
         J.coef_off[ci] = coef_bytes; coef_bytes += nb * 128;
-        (ci ? chroma_blocks : luma_blocks) += nb;
-        J.px_off[ci] = px_bytes; px_bytes += (qs_hip_plane_bytes(job->wblk[ci], job->hblk[ci]) + 255) & ~(size_t)255;
+        J.px_off[ci] = px_bytes; px_bytes += 2 * plane_stride(job->wblk[ci], job->hblk[ci]);   // two planes: fused pass A ping-pongs
         const uint16_t* q = job->quant[ci];
         J.cst[ci] = -1;
         for (size_t k = 0; k < qtabs.size() && J.cst[ci] < 0; ++k)
@@ -139,9 +141,16 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
   ComputeSlot slot(current_device());                        // (released when this group's kernels have finished)
 
   auto coef_of = [&](int g, int ci) { return reinterpret_cast<int16_t*>(coef.as<char>() + cj[g].coef_off[ci]); };
-  auto plane_of = [&](int g, int ci) { return px.as<uint8_t>() + cj[g].px_off[ci]; };
+  // Every component has two pixel planes: a pass B that is followed by another pass A (the next iteration's, or the
+  // refresh pass the later stages read) writes that plane itself -- fused pass A -- and the two swap roles.
+  std::vector<unsigned char> cur((size_t)G * 3, 0);          // which of its two planes is component (g, ci)'s current one
+  auto plane_at = [&](int g, int ci, int which_) {
+    return px.as<uint8_t>() + cj[g].px_off[ci] + (which_ ? plane_stride(jobs[which[g]]->wblk[ci], jobs[which[g]]->hblk[ci]) : 0);
+  };
+  auto plane_of = [&](int g, int ci) { return plane_at(g, ci, cur[(size_t)g * 3 + ci]); };
   auto lowres_of = [&](int g) { return cj[g].sub ? px.as<uint8_t>() + cj[g].l_off : plane_of(g, 0); };
-  auto make_set = [&](QsPlaneSet& set, int ci0, int ci1) {
+  // next(g, ci): does the coming pass B write this plane's successor?
+  auto make_set = [&](QsPlaneSet& set, int ci0, int ci1, const std::function<bool(int, int)>& next) {
     memset(&set, 0, sizeof set);
     int w = 0, n = 0;
     for (int g = 0; g < G; ++g)
@@ -153,6 +162,7 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
         R.cst = cst.as<QsConsts>() + cj[g].cst[ci];
         R.coef = coef_of(g, ci);
         R.plane = plane_of(g, ci);
+        R.plane_next = next(g, ci) ? plane_at(g, ci, !cur[(size_t)g * 3 + ci]) : nullptr;
         R.status = status.as<int32_t>() + g * 3 + ci;
         R.wblk = job->wblk[ci]; R.hblk = job->hblk[ci]; R.pitch = qs_plane_pitch(job->wblk[ci]);
         R.mode = QS_PLANE_REP_TOP | QS_PLANE_REP_BOT | (comp_rebalance(job, ci, flags) ? QS_PLANE_REBALANCE : 0);
@@ -160,17 +170,22 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
     set.n = n;
     for (int i = n; i < QS_MAX_PLANES + 2; ++i) set.wave0[i] = w;
   };
+  auto flip = [&](int ci0, int ci1, const std::function<bool(int, int)>& next) {
+    for (int g = 0; g < G; ++g) for (int ci = ci0; ci < ci1; ++ci) if (next(g, ci)) cur[(size_t)g * 3 + ci] ^= 1;
+  };
+  const std::function<bool(int, int)> none = [](int, int) { return false; }, all = [](int, int) { return true; };
   QsPlaneSet set;
 
-  // ---- luma: niter iterations, then the refresh pass the chroma stages read (reference :2495, :2622).
-  // The +-1023 clamp comes after that refresh (reference :2668-2689 sits behind the loop).
-  make_set(set, 0, 1);
+  // ---- luma: pass A once, niter iterations; the last one also writes the refresh the chroma stages read (reference
+  // :2495, :2622) and carries the +-1023 clamp: the fused IDCT reads the unclamped coefficients the kernel holds, so
+  // the refresh is that of the unclamped luma, as in the reference, whose clamp sits behind its loop (:2668-2689).
+  make_set(set, 0, 1, none);
+  qs_launch_idct_set(set, 1, s);
   for (int it = 0; it < niter; ++it) {
-    qs_launch_idct_set(set, it == 0, s);
-    qs_launch_smooth_set(set, diag, 0, s);
+    make_set(set, 0, 1, all);
+    qs_launch_smooth_set(set, diag, it == niter - 1, s);
+    flip(0, 1, all);
   }
-  qs_launch_idct_set(set, 0, s);
-  qs_launch_clamp(coef_of(0, 0), luma_blocks, s);
   for (int g = 0; g < G; ++g) {                              // image2 (reference :2753-2815)
     const qs_hip_job* job = jobs[which[g]];
     if (cj[g].sub)
@@ -178,35 +193,25 @@ static int run_coupled(qs_hip_job* const* jobs, const std::vector<int>& which, i
                            job->hsamp[0], job->vsamp[0], s);
   }
 
-  // ---- chroma.  A job that is upsampled afterwards takes one more refresh pass (and its clamp moves
-  // behind it); jobs of both kinds may share a group, so the extra pass runs on a set of its own.
-  make_set(set, 1, 3);
+  // ---- chroma.  A job that is upsampled afterwards needs one more refresh (the last pass B writes it); jobs of
+  // both kinds may share a group.  The clamp rides on the last iteration for all of them.
   QsPlaneAux lowres;
   memset(&lowres, 0, sizeof lowres);
   for (int g = 0; g < G; ++g) lowres.p[2 * g] = lowres.p[2 * g + 1] = lowres_of(g);
-  bool any_up = false, all_up = true;
-  for (int g = 0; g < G; ++g) { any_up |= cj[g].upsample; all_up &= cj[g].upsample; }
+  bool any_up = false;
+  for (int g = 0; g < G; ++g) any_up |= cj[g].upsample;
+  const std::function<bool(int, int)> ups = [&](int g, int) { return cj[g].upsample; };
+  make_set(set, 1, 3, none);
+  qs_launch_idct_set(set, 1, s);
   for (int it = 0; it < niter; ++it) {
-    qs_launch_idct_set(set, it == 0, s);
+    const std::function<bool(int, int)>& next = it < niter - 1 ? all : ups;
+    make_set(set, 1, 3, next);
     if (joint)                                               // JOINT_YUV acts through the low-res luma plane (reference :2636)
       qs_launch_joint_set(set, lowres, 0, 0, s);
-    qs_launch_smooth_set(set, diag, it == niter - 1 && !any_up, s);
+    qs_launch_smooth_set(set, diag, it == niter - 1, s);
+    flip(1, 3, next);
   }
   if (any_up) {
-    if (all_up) {
-      qs_launch_idct_set(set, 0, s);
-      qs_launch_clamp(coef_of(0, 1), chroma_blocks, s);
-    } else {
-      for (int g = 0; g < G; ++g)
-        for (int ci = 1; ci < 3; ++ci) {
-          const qs_hip_job* job = jobs[which[g]];
-          if (cj[g].upsample)
-            qs_launch_idct_plane(cst.as<QsConsts>() + cj[g].cst[ci], coef_of(g, ci), plane_of(g, ci), job->wblk[ci], job->hblk[ci],
-                                 0, 1, 1, status.as<int32_t>() + g * 3 + ci, s);
-        }
-      qs_launch_clamp(coef_of(0, 1), chroma_blocks, s);     // (clamping is idempotent and independent of the refresh order
-                                                              //  for the jobs without one)
-    }
     for (int g = 0; g < G; ++g) {                            // UPSAMPLE_UV (reference :2691-2752)
       if (!cj[g].upsample) continue;
       const qs_hip_job* job = jobs[which[g]];

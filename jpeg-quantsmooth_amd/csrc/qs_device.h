@@ -61,6 +61,10 @@ struct QsPlaneRef {
   int32_t* status;       // range-check flag (pass A, first iteration)
   int32_t wblk, hblk, pitch;
   int32_t mode;          // QS_PLANE_* bits
+  // Pass B of iteration n writes the pixel plane of iteration n + 1 itself (the IDCT of the block's final
+  // coefficients, which it holds in LDS anyway): a SECOND plane of the same geometry, because the other blocks of
+  // the launch still read `plane` (Jacobi iteration).  null: no next plane (last iteration; pass A runs separately).
+  uint8_t* plane_next;
 };
 enum {
   QS_PLANE_REBALANCE = 1,  // pass B: run the rebalance step on this plane

@@ -19,6 +19,7 @@ using namespace qsj;
 // the careful order from its untouched host input.
 
 namespace {
+static size_t plane_stride(int wb, int hb) { return (qs_hip_plane_bytes(wb, hb) + 255) & ~(size_t)255; }
 // One device plane of a set: a whole component, or a band of block rows of a very large
 // one (rows [src_row0, src_row0 + hb) of the source, of which [keep0, keep1) are results:
 // the rest is halo, see split_rows).
@@ -108,7 +109,7 @@ void qsj::fused_stage_sizes(const qs_hip_job* job, int niter, std::vector<size_t
   partition(one, std::vector<int>{0}, niter, groups, split);
   for (const FGroup& G : groups) {
     size_t n = 0, px = 0;
-    for (const FPlane& P : G.planes) { n += P.cbytes; px += (qs_hip_plane_bytes(P.wb, P.hb) + 255) & ~(size_t)255; }
+    for (const FPlane& P : G.planes) { n += P.cbytes; px += 2 * plane_stride(P.wb, P.hb); }
     coef_bytes.push_back(n);
     px_bytes.push_back(px);
   }
@@ -140,7 +141,7 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
     std::vector<const uint16_t*> qtabs;
     for (FPlane& P : G.planes) {
       P.coef_off = coef_bytes; coef_bytes += P.cbytes;
-      P.px_off = px_bytes; px_bytes += (qs_hip_plane_bytes(P.wb, P.hb) + 255) & ~(size_t)255;
+      P.px_off = px_bytes; px_bytes += 2 * plane_stride(P.wb, P.hb);       // two planes: pass B writes the next iteration's
       const uint16_t* q = jobs[P.job]->quant[P.ci];
       for (size_t k = 0; k < qtabs.size() && P.cst < 0; ++k)
         if (!memcmp(qtabs[k], q, 64 * sizeof(uint16_t))) P.cst = (int)k;
@@ -188,8 +189,16 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
       R.mode = QS_PLANE_REP_TOP | QS_PLANE_REP_BOT | (comp_rebalance(jobs[P.job], P.ci, flags) ? QS_PLANE_REBALANCE : 0);
     }
     for (int i = np; i < QS_MAX_PLANES + 2; ++i) set.wave0[i] = w;
+    // pass A once (dequantise, range check, first pixel planes); every pass B but the last writes the next
+    // iteration's planes itself (fused pass A, ping-pong between the two planes of each FPlane)
+    qs_launch_idct_set(set, 1, G.s);
     for (int it = 0; it < niter; ++it) {
-      qs_launch_idct_set(set, it == 0, G.s);
+      for (int i = 0; i < np; ++i) {
+        uint8_t* a = G.px.as<uint8_t>() + G.planes[i].px_off;
+        uint8_t* b = a + plane_stride(G.planes[i].wb, G.planes[i].hb);
+        set.ref[i].plane = (it & 1) ? b : a;
+        set.ref[i].plane_next = it == niter - 1 ? nullptr : (it & 1) ? a : b;
+      }
       qs_launch_smooth_set(set, diag, it == niter - 1, G.s);
     }
     HIP_TRY(hipGetLastError());

@@ -36,7 +36,7 @@ using namespace qsj;
 namespace {
 
 struct Comp {            // per-component device state (kept until the job ends)
-  DevBuf coef, plane, cst, status, up, px;
+  DevBuf coef, plane, plane2, cst, status, up, px;   // plane2: the second pixel plane of the fused schedule (pass B writes the next iteration's)
   PinnedBuf stage;           // pinned upload staging, held until the job's streams are drained
   PinnedBuf hstatus;         // range-check flag on its way back
   Download down, down_up;    // results on their way back
@@ -163,9 +163,18 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
     const bool joint = have_llow && (flags & QS_JOINT_YUV);
     const int plane_flags = flags & (QS_DIAGONALS | QS_NO_REBALANCE | QS_NO_REBALANCE_UV);
     bool clamped = false;
+    // Fused schedule: every pass B that is followed by another pass A (the next iteration's, or the refresh-only
+    // pass) writes that pass's pixel plane itself, into a second plane (C.plane and C.plane2 swap roles); the
+    // stand-alone pass A then only runs for iteration 0.  Not for LOW_QUALITY (no recovery kernel), and not when the
+    // second plane cannot be had (the unfused order is the fall-back, like the reference's own, :2551-2566).
+    bool fuse = !(flags & QS_LOW_QUALITY) && iters + extra > 1;
+    if (fuse && C.plane2.alloc(qs_hip_plane_bytes(wb, hb)) != hipSuccess) { (void)hipGetLastError(); fuse = false; }
+    bool have_next = false;                              // this iteration's plane was written by the previous pass B
     for (int it = 0; it < iters + extra; ++it) {
-      if (int r = qs_hip_idct_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), wb, hb,
-                                    it == 0, 1, 1, C.status.as<int32_t>(), s)) return r;
+      if (!have_next)
+        if (int r = qs_hip_idct_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), wb, hb,
+                                      it == 0, 1, 1, C.status.as<int32_t>(), s)) return r;
+      have_next = false;
       if (it == 0 && !eager) {                           // reference :2610
         int32_t bad = 0;
         HIP_TRY(hipMemcpyAsync(&bad, C.status.p, sizeof(bad), hipMemcpyDeviceToHost, s));
@@ -190,8 +199,17 @@ int qsj::run_job(qs_hip_job* job, int flags, int niter, int progprec,
         if (joint)
           if (int r = qs_hip_joint_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), d_llow.as<uint8_t>(),
                                          wb, hb, 0, 0, s)) return r;
-        if (int r = qs_hip_smooth_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), wb, hb,
-                                        plane_flags, luma, last, s)) return r;
+        if (fuse && it + 1 < iters + extra) {
+          // (the +-1023 clamp may ride on the last iteration's launch even when the refresh-only pass follows: the
+          //  fused IDCT reads the unclamped coefficients the kernel holds, the clamp applies to what it stores)
+          const int clamp_now = it == iters - 1;
+          if (int r = qs_hip_smooth_plane_next(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), C.plane2.as<uint8_t>(),
+                                               wb, hb, plane_flags, luma, clamp_now, 1, 1, s)) return r;
+          DevBuf t; t.take(C.plane); C.plane.take(C.plane2); C.plane2.take(t);
+          have_next = true;
+          if (clamp_now) clamped = true;
+        } else if (int r = qs_hip_smooth_plane(C.cst.p, C.coef.as<int16_t>(), C.plane.as<uint8_t>(), wb, hb,
+                                               plane_flags, luma, last, s)) return r;
       }
       if (last) clamped = true;
       if (progress) {                                    // reference :2656-2664

@@ -7,9 +7,11 @@
 
 void qs_launch_idct_plane(const QsConsts* cst, int16_t* coef, uint8_t* plane, int wblk, int hblk,
                           int first, int rep_top, int rep_bot, int* status, hipStream_t s);
-void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* plane, int wblk, int hblk,
-                            int diag, int rebalance, int final_clamp, int blk_begin, int blk_end, hipStream_t s);
-// one launch over a set of whole planes (job / batch layer)
+// plane_next (may be null): the pixel plane of the NEXT iteration, written by pass B itself (fused pass A) -- a second
+// plane of the same geometry; rep_top / rep_bot as in qs_launch_idct_plane
+void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* plane, uint8_t* plane_next, int rep_top, int rep_bot,
+                            int wblk, int hblk, int diag, int rebalance, int final_clamp, int blk_begin, int blk_end, hipStream_t s);
+// one launch over a set of whole planes (job / batch layer); QsPlaneRef::plane_next per plane
 void qs_launch_idct_set(const QsPlaneSet& set, int first, hipStream_t s);
 void qs_launch_smooth_set(const QsPlaneSet& set, int diag, int final_clamp, hipStream_t s);
 void qs_launch_clamp(int16_t* coef, size_t nblk, hipStream_t s);

@@ -64,14 +64,16 @@ extern "C" int qs_hip_idct_plane(const void* d_consts, int16_t* d_coef, uint8_t*
 }
 
 static int smooth_rows(const void* d_consts, int16_t* d_coef, const uint8_t* d_plane, int wblk, int hblk,
-                       int row0, int row1, int flags, int luma, int final_clamp, void* stream, const char* who) {
+                       int row0, int row1, int flags, int luma, int final_clamp, void* stream, const char* who,
+                       uint8_t* d_next = nullptr, int rep_top = 1, int rep_bot = 1) {
   if (int r = check_plane_args(d_coef, d_plane, wblk, hblk, who)) return r;
+  if (d_next == d_plane) return qs_fail(QS_HIP_EINVAL, "%s: the next plane must be a different buffer (other blocks still read the current one)", who);
   if (!d_consts) return qs_fail(QS_HIP_EINVAL, "%s: null consts", who);
   if (row0 < 0 || row1 > hblk || row0 > row1) return qs_fail(QS_HIP_EINVAL, "%s: bad row range %d..%d", who, row0, row1);
   if (flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV | QS_LOW_QUALITY))
     return qs_fail(QS_HIP_ENOTSUP, "%s: flags 0x%x are handled by qs_hip_joint_plane / qs_hip_lowq_plane", who, flags);
   int rebalance = !(flags & QS_NO_REBALANCE) && (luma || !(flags & QS_NO_REBALANCE_UV)); // reference :1567-1568
-  qs_launch_smooth_plane(static_cast<const QsConsts*>(d_consts), d_coef, d_plane, wblk, hblk,
+  qs_launch_smooth_plane(static_cast<const QsConsts*>(d_consts), d_coef, d_plane, d_next, rep_top, rep_bot, wblk, hblk,
                          (flags & QS_DIAGONALS) != 0, rebalance, final_clamp, row0 * wblk, row1 * wblk,
                          static_cast<hipStream_t>(stream));
   return launch_status(who);
@@ -80,6 +82,12 @@ static int smooth_rows(const void* d_consts, int16_t* d_coef, const uint8_t* d_p
 extern "C" int qs_hip_smooth_plane(const void* d_consts, int16_t* d_coef, const uint8_t* d_plane,
                                    int wblk, int hblk, int flags, int luma, int final_clamp, void* stream) {
   return smooth_rows(d_consts, d_coef, d_plane, wblk, hblk, 0, hblk, flags, luma, final_clamp, stream, "qs_hip_smooth_plane");
+}
+
+extern "C" int qs_hip_smooth_plane_next(const void* d_consts, int16_t* d_coef, const uint8_t* d_plane, uint8_t* d_plane_next,
+                                        int wblk, int hblk, int flags, int luma, int final_clamp, int rep_top, int rep_bot, void* stream) {
+  return smooth_rows(d_consts, d_coef, d_plane, wblk, hblk, 0, hblk, flags, luma, final_clamp, stream, "qs_hip_smooth_plane_next",
+                     d_plane_next, rep_top, rep_bot);
 }
 
 extern "C" int qs_hip_smooth_rows(const void* d_consts, int16_t* d_coef, const uint8_t* d_plane,
@@ -101,6 +109,9 @@ static int build_plane_set(const qs_hip_plane_ref* refs, int n, int flags, QsPla
     QsPlaneRef& R = set.ref[i];
     R.cst = static_cast<const QsConsts*>(r.d_consts);
     R.coef = r.d_coef; R.plane = r.d_plane; R.status = r.d_status;
+    R.plane_next = r.d_plane_next;
+    if (r.d_plane_next && r.d_plane_next == r.d_plane)
+      return qs_fail(QS_HIP_EINVAL, "%s: d_plane_next must be a different buffer (other blocks still read d_plane)", who);
     R.wblk = r.wblk; R.hblk = r.hblk; R.pitch = qs_plane_pitch(r.wblk);
     R.mode = ((!(flags & QS_NO_REBALANCE) && (r.luma || !(flags & QS_NO_REBALANCE_UV))) ? QS_PLANE_REBALANCE : 0) |
              ((r.band & 1) ? 0 : QS_PLANE_REP_TOP) | ((r.band & 2) ? 0 : QS_PLANE_REP_BOT);

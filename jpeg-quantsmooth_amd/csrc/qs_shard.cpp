@@ -177,6 +177,8 @@ static int before_overwrite(Bands& bands, size_t d) {
   return QS_HIP_OK;
 }
 
+static size_t plane_stride(int wb, int hb) { return (qs_hip_plane_bytes(wb, hb) + 255) & ~(size_t)255; }
+
 // the per-band constant blocks: one per distinct quant table among the band's planes
 static int upload_consts(Band& B, const qs_hip_job* job, int flags) {
   std::vector<const uint16_t*> qtabs;
@@ -202,7 +204,7 @@ static int stage_band(Band& B, const qs_hip_job* job, int flags) {
   for (BandPlane& P : B.planes) {
     P.cbytes = (size_t)P.wb * P.hb * 128;
     P.coef_off = coef_bytes; coef_bytes += P.cbytes;
-    P.px_off = px_bytes; px_bytes += (qs_hip_plane_bytes(P.wb, P.hb) + 255) & ~(size_t)255;
+    P.px_off = px_bytes; px_bytes += 2 * plane_stride(P.wb, P.hb);   // two planes each (the set route ping-pongs: fused pass A)
   }
   const int np = (int)B.planes.size();
   HIP_TRY(B.coef.alloc(std::max<size_t>(coef_bytes, 64)));
@@ -314,22 +316,35 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
 
   const int diag = (flags & QS_DIAGONALS) != 0;
   if (trace_on()) for (Band& B : bands.b) { HIP_TRY(hipSetDevice(B.dev)); HIP_TRY(hipEventRecord(B.evT0, B.s)); }
+  // Pass A runs once; every pass B but the last writes the next iteration's pixel planes itself (fused pass A) into
+  // the band's second set of planes -- plane (it & 1) is read, plane ((it + 1) & 1) written.
   for (int it = 0; it < niter; ++it) {
-    for (size_t d = 0; d < bands.b.size(); ++d) {
-      Band& B = bands.b[d];
-      HIP_TRY(hipSetDevice(B.dev));
-      if (int r = before_overwrite(bands, d)) return r;
-      qs_launch_idct_set(B.set, it == 0, B.s);
-    }
-    // one pixel row per component and band edge
+    const int cur = it & 1;
+    if (it == 0)
+      for (size_t d = 0; d < bands.b.size(); ++d) {
+        Band& B = bands.b[d];
+        HIP_TRY(hipSetDevice(B.dev));
+        if (int r = before_overwrite(bands, d)) return r;
+        qs_launch_idct_set(B.set, 1, B.s);
+      }
+    // one pixel row per component and band edge, of the planes this iteration's pass B reads
     if (int r = exchange(bands, job->ncomp, [&](int d, int ci, uint8_t** p, int* wb, int* hb) {
           const BandPlane* P = find_plane(bands.b[d], ci);
           if (!P) return false;
-          *p = bands.b[d].px.as<uint8_t>() + P->px_off; *wb = P->wb; *hb = P->hb;
+          *p = bands.b[d].px.as<uint8_t>() + P->px_off + (cur ? plane_stride(P->wb, P->hb) : 0); *wb = P->wb; *hb = P->hb;
           return true;
         })) return r;
-    for (Band& B : bands.b) {
+    for (size_t d = 0; d < bands.b.size(); ++d) {
+      Band& B = bands.b[d];
       HIP_TRY(hipSetDevice(B.dev));
+      for (size_t i = 0; i < B.planes.size(); ++i) {
+        uint8_t* a = B.px.as<uint8_t>() + B.planes[i].px_off;
+        uint8_t* b = a + plane_stride(B.planes[i].wb, B.planes[i].hb);
+        B.set.ref[i].plane = cur ? b : a;
+        B.set.ref[i].plane_next = it == niter - 1 ? nullptr : cur ? a : b;
+      }
+      // the planes about to be written are the ones the neighbours pulled their halo rows from one iteration ago
+      if (it < niter - 1) if (int r = before_overwrite(bands, d)) return r;
       qs_launch_smooth_set(B.set, diag, it == niter - 1, B.s);
     }
   }
@@ -449,7 +464,7 @@ static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::
         qs_launch_lowq(ref(B, 0).cst, ref(B, 0).coef, ref(B, 0).plane, P.wb, P.hb, comp_rebalance(job, 0, flags), 0,
                        2.0f * sqrtf(0.5f), B.s);
       else
-        qs_launch_smooth_plane(ref(B, 0).cst, ref(B, 0).coef, ref(B, 0).plane, P.wb, P.hb, diag,
+        qs_launch_smooth_plane(ref(B, 0).cst, ref(B, 0).coef, ref(B, 0).plane, nullptr, 1, 1, P.wb, P.hb, diag,
                                comp_rebalance(job, 0, flags), 0, 0, P.wb * P.hb, B.s);
     }
   }
@@ -493,7 +508,7 @@ static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::
           else qs_launch_lowq(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, P.wb, P.hb, reb, last, 2.0f * sqrtf(0.5f), B.s);
         } else {
           if (joint) qs_launch_joint(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, lowres(B), P.wb, P.hb, 0, 0, B.s);
-          qs_launch_smooth_plane(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, P.wb, P.hb, diag, reb, last,
+          qs_launch_smooth_plane(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, nullptr, 1, 1, P.wb, P.hb, diag, reb, last,
                                  0, P.wb * P.hb, B.s);
         }
       }

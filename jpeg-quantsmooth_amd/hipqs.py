@@ -63,7 +63,8 @@ class Job(C.Structure):
 class PlaneRef(C.Structure):
     """qs_hip_plane_ref: one plane of a plane-set launch (device pointers)"""
     _fields_ = [("d_consts", C.c_void_p), ("d_coef", C.c_void_p), ("d_plane", C.c_void_p), ("d_status", C.c_void_p),
-                ("wblk", C.c_int32), ("hblk", C.c_int32), ("luma", C.c_int32), ("band", C.c_int32)]
+                ("wblk", C.c_int32), ("hblk", C.c_int32), ("luma", C.c_int32), ("band", C.c_int32),
+                ("d_plane_next", C.c_void_p)]
 
 
 MAX_PLANES = 56
@@ -94,6 +95,8 @@ ABI = {
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "qs_hip_smooth_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_smooth_plane_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_smooth_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_idct_planes": (C.c_int, [C.POINTER(PlaneRef), C.c_int, C.c_int, C.c_void_p]),
@@ -291,16 +294,24 @@ class HipQS:
         self._check(self.lib.qs_hip_smooth_plane(d_consts, d_coef, d_plane, wblk, hblk, flags,
                                                  int(luma), int(final_clamp), stream))
 
+    def smooth_plane_next(self, d_consts, d_coef, d_plane, d_plane_next, wblk, hblk, flags, luma=1, final_clamp=0,
+                          rep_top=1, rep_bot=1, stream=None):
+        """pass B that also writes the NEXT iteration's pixel plane (fused pass A) into d_plane_next"""
+        self._check(self.lib.qs_hip_smooth_plane_next(d_consts, d_coef, d_plane, d_plane_next, wblk, hblk, flags,
+                                                      int(luma), int(final_clamp), int(rep_top), int(rep_bot), stream))
+
     @staticmethod
     def plane_refs(planes):
-        """[(d_consts, d_coef, d_plane, d_status, wblk, hblk, luma[, band])] -> ctypes array for the *_planes
-        calls; band: bit 0 / bit 1 = the top / bottom apron row is a halo row (a band of a sharded plane)"""
+        """[(d_consts, d_coef, d_plane, d_status, wblk, hblk, luma[, band[, d_plane_next]])] -> ctypes array for the
+        *_planes calls; band: bit 0 / bit 1 = the top / bottom apron row is a halo row (a band of a sharded plane);
+        d_plane_next: the plane qs_hip_smooth_planes writes the next iteration's pixels into (None: none)"""
         arr = (PlaneRef * len(planes))()
         for r, p in zip(arr, planes):
             cst, coef, plane, status, wb, hb, luma = p[:7]
             r.d_consts, r.d_coef, r.d_plane, r.d_status = cst, coef, plane, status
             r.wblk, r.hblk, r.luma = wb, hb, int(luma)
             r.band = int(p[7]) if len(p) > 7 else 0
+            r.d_plane_next = p[8] if len(p) > 8 else None
         return arr
 
     def idct_planes(self, refs, first, stream=None):

@@ -204,6 +204,57 @@ def test_gpu_plane_layer_device_resident(gpu, oracle, synth):
         assert np.array_equal(d_coef.cpu().numpy(), want)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"QS_HIP_DP": "0"}], ids=["launcher's choice (small-plane kernel + pass A behind it)", "one block per lane (fused epilogue)"])
+@pytest.mark.parametrize("size", [(256, 192), (1016, 520), (2048, 1032)])
+def test_gpu_fused_pass_a_equals_separate_launches(size, env):
+    """qs_hip_smooth_plane_next (pass B that also writes the next iteration's pixel plane) against
+    qs_hip_smooth_plane followed by qs_hip_idct_plane: same coefficients, and the next plane byte for byte --
+    interior, apron columns, replicated apron rows, and with the halo-side apron rows LEFT ALONE when rep_top /
+    rep_bot are 0 (bands).  Also with the +-1023 clamp riding on the fused launch: the pixels must be those of the
+    UNCLAMPED coefficients (reference :2668-2689 clamps behind the refresh pass).  Fresh process per kernel form."""
+    code = r"""
+import sys, numpy as np, torch
+import jpegqs_pkg
+pkg = jpegqs_pkg.load(); gpu = pkg.HipQS()
+w, h = %d, %d
+coef, quant = pkg.synth.synth_gray(w, h, 50, seed=5)
+coef = coef.copy(); coef[::3, ::5, 1:9] *= 6          # some coefficients beyond +-1023 after dequantisation: the clamp matters
+quant = quant.copy(); quant[1:9] = np.minimum(quant[1:9] * 3, 255)
+hb, wb = coef.shape[:2]
+dev = torch.device("cuda:0")
+s = torch.cuda.current_stream().cuda_stream
+for flags in (0, 1):
+    for rep_top, rep_bot, clamp in ((1, 1, 0), (0, 1, 0), (1, 0, 1), (0, 0, 1)):
+        cst = torch.from_numpy(gpu.consts_build(quant, flags)).to(dev)
+        st = torch.zeros(1, dtype=torch.int32, device=dev)
+        def fresh():
+            c = torch.from_numpy(coef.copy()).to(dev)
+            p = torch.full((gpu.plane_bytes(wb, hb),), 77, dtype=torch.uint8, device=dev)
+            gpu.idct_plane(cst.data_ptr(), c.data_ptr(), p.data_ptr(), wb, hb, 1, 1, 1, st.data_ptr(), s)
+            return c, p
+        # separate launches: pass B (no clamp), pass A into a second plane, then the clamp
+        c1, p1 = fresh()
+        n1 = torch.full_like(p1, 201)
+        gpu.smooth_plane(cst.data_ptr(), c1.data_ptr(), p1.data_ptr(), wb, hb, flags, 1, 0, s)
+        gpu.idct_plane(cst.data_ptr(), c1.data_ptr(), n1.data_ptr(), wb, hb, 0, rep_top, rep_bot, st.data_ptr(), s)
+        if clamp:
+            gpu.clamp_plane(c1.data_ptr(), wb, hb, s)
+        # fused
+        c2, p2 = fresh()
+        n2 = torch.full_like(p2, 201)
+        gpu.smooth_plane_next(cst.data_ptr(), c2.data_ptr(), p2.data_ptr(), n2.data_ptr(), wb, hb, flags, 1, clamp, rep_top, rep_bot, s)
+        torch.cuda.synchronize()
+        assert torch.equal(c1, c2), ("coefficients", flags, rep_top, rep_bot, clamp)
+        assert torch.equal(p1, p2), "the current plane must not be written"
+        assert torch.equal(n1, n2), ("next plane", flags, rep_top, rep_bot, clamp, int((n1 != n2).sum()))
+        if clamp:
+            assert int(c2.abs().max()) <= 1023
+print("ok")
+""" % (size[0], size[1])
+    assert "ok" in _run_py(code, env)
+
+
 def test_gpu_large_plane_properties(gpu, oracle, synth):
     """2048x2048 (65,536 blocks): too slow to check everywhere on the scalar
     oracle in CI, so check (a) a band of block rows exactly, using the fact that
