@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--niter", type=int, default=3)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--jpeg-quality", type=int, default=50)
+    ap.add_argument("--print-trace", action="store_true", help="print the QS_HIP_TRACE lines of the last timed call to stderr")
     a = ap.parse_args()
     devices = [int(d) for d in a.devices.replace("+", ",").split(",") if d != ""]   # ("+" works too: tools/session.sh turns commas into spaces)
     os.environ["QS_HIP_TRACE"] = "1"
@@ -82,6 +83,8 @@ def main():
         ms, got, tr = call(sharded)
         if rep >= warm:
             times.append(ms); traces.append(tr)
+    if a.print_trace and traces:
+        print(traces[-1], file=sys.stderr)
     out = {"entry": "qs_hip_do_quantsmooth_sharded" if sharded else "qs_hip_do_quantsmooth",
            "devices": devices, "image": f"{a.size}x{a.size} luma, q={a.quality} niter={a.niter}",
            "ms_per_image": float(np.median(times)), "ms_all": [round(t, 2) for t in times],
