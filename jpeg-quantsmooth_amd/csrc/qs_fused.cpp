@@ -34,6 +34,13 @@ struct FGroup {
   Download down;                          // results on their way back
   hipStream_t s = nullptr;
   size_t blocks = 0, coef_bytes = 0;
+  // QS_HIP_TRACE only: device timestamps "input is on the device" / "kernels done" / "results are in pinned host memory"
+  hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
+  float t_ms[3] = {0, 0, 0};              // ... in ms after the call's first event, read when the group is drained
+  FGroup() = default;
+  FGroup(const FGroup&) = delete;
+  FGroup& operator=(const FGroup&) = delete;
+  ~FGroup() { for (hipEvent_t& e : tev) if (e) { (void)hipEventDestroy(e); e = nullptr; } }
   // everything queued on the group's stream has completed: give the arenas back
   void release_transients(bool keep_stage) {
     coef.release(); px.release(); cst.release(); status.release();
@@ -133,9 +140,12 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
   // ---- per group: upload, niter x (pass A, pass B), status readback, download into pinned memory
   const int diag = (flags & QS_DIAGONALS) != 0;
   size_t gi = 0;
+  hipEvent_t t_first = nullptr;                              // QS_HIP_TRACE: time zero of the per-group device timestamps
+  struct EvGuard { hipEvent_t& e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } t_first_guard{t_first};
   auto enqueue = [&](FGroup& G) -> int {
     const double t_g0 = wall_ms();
     G.s = lease.p->get_ready((int)(gi++ % 3));
+    if (trace_on() && !t_first) { HIP_TRY(hipEventCreate(&t_first)); HIP_TRY(hipEventRecord(t_first, G.s)); }   // time zero: before the first upload
     const int np = (int)G.planes.size();
     size_t coef_bytes = 0, px_bytes = 0;
     std::vector<const uint16_t*> qtabs;
@@ -171,6 +181,10 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
       fprintf(stderr, "qs_hip trace: fused  group %zu: alloc+consts %.2f ms, upload of %.1f MiB in %zu piece(s) %.2f ms (%s)\n",
               gi, t_up0 - t_g0, coef_bytes / 1048576.0, pieces.size(), wall_ms() - t_up0, G.stage.p ? "staged" : "direct");
     HIP_TRY(hipMemsetAsync(G.status.p, 0, (size_t)np * sizeof(int32_t), G.s));
+    if (trace_on()) {
+      for (hipEvent_t& e : G.tev) HIP_TRY(hipEventCreate(&e));
+      HIP_TRY(hipEventRecord(G.tev[0], G.s));
+    }
 
     QsPlaneSet set;
     memset(&set, 0, sizeof set);
@@ -202,10 +216,12 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
       qs_launch_smooth_set(set, diag, it == niter - 1, G.s);
     }
     HIP_TRY(hipGetLastError());
+    if (G.tev[1]) HIP_TRY(hipEventRecord(G.tev[1], G.s));
     // pinned: a pageable destination would make this call wait for the whole stream
     if (!G.hstatus.alloc((size_t)np * sizeof(int32_t))) return qs_fail(QS_HIP_ENOMEM, "out of pinned host memory");
     HIP_TRY(hipMemcpyAsync(G.hstatus.p, G.status.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, G.s));
     HIP_TRY(G.down.issue(G.coef.p, coef_bytes, G.s, rows_active()));       // to pinned memory, right behind the kernels
+    if (G.tev[2]) HIP_TRY(hipEventRecord(G.tev[2], G.s));
     // a band job is scattered band by band; without the staging copy of its input (pinned memory
     // exhausted) nothing could be restored should a later band trip the range check: hold it back
     if (!G.stage.p) for (int ji : G.jobs) if (split[ji]) defer[ji] = 1;
@@ -235,6 +251,8 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
     if (!G.stage.p) HIP_TRY(G.down.land(G.coef.p, G.s));        // no restore copy: land first, write afterwards
     HIP_TRY(G.down.finish(G.coef.p, back, G.s, G.stage.p != nullptr));
     for (int ji : G.jobs) ++ndone[ji];
+    if (G.tev[2] && t_first && hipEventSynchronize(G.tev[2]) == hipSuccess)
+      for (int k = 0; k < 3; ++k) if (hipEventElapsedTime(&G.t_ms[k], t_first, G.tev[k]) != hipSuccess) { (void)hipGetLastError(); G.t_ms[k] = -1; }
     // the group's stream work is complete: recycle its device arenas and download staging now, so
     // that memory in flight is bounded by the window below and not by the size of the batch.  The
     // upload staging of a band job stays (it is the restore copy): that is one image's worth.
@@ -302,9 +320,14 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
     rerun.push_back(ji);
     if (scattered[ji]) restore_job(ji);                      // (otherwise the host input is still untouched)
   }
-  if (trace_on())
+  if (trace_on()) {
     fprintf(stderr, "qs_hip trace: fused  %zu job(s) in %zu group(s)  enqueue %.2f ms  drain+download %.2f ms  (%zu re-run)\n",
             which.size(), groups.size(), t_enq - t_start, wall_ms() - t_enq, rerun.size());
+    // device timeline per group, ms after the first group's stream work began: input on the device / kernels done / results in pinned memory
+    fprintf(stderr, "qs_hip trace: fused  device timeline (upload done, kernels done, download done):");
+    for (const FGroup& G : groups) fprintf(stderr, " [%.2f %.2f %.2f]", G.t_ms[0], G.t_ms[1], G.t_ms[2]);
+    fprintf(stderr, "\n");
+  }
   for (int ji : which) {
     if (bad_job[ji]) continue;
     for (int ci = 0; ci < jobs[ji]->ncomp; ++ci)           // reference :2851-2859

@@ -107,6 +107,10 @@ def main():
             m2 = re.search(r"fused  .*enqueue ([0-9.]+) ms  drain\+download ([0-9.]+) ms", tr)
             if m2:
                 out["phases_ms"] = {"enqueue": float(m2.group(1)), "drain_and_download": float(m2.group(2))}
+                m3 = re.search(r"device timeline \(upload done, kernels done, download done\):((?: \[[-0-9. ]+\])+)", tr)
+                if m3:   # per band, ms after the first band's upload (HIP events on the bands' streams)
+                    out["bands_device_ms"] = [dict(zip(("upload_done", "kernels_done", "download_done"), (float(v) for v in b.split())))
+                                              for b in re.findall(r"\[([-0-9. ]+)\]", m3.group(1))]
                 break
     # a cheap exact check against the CPU oracle: 16 block rows top / middle / bottom
     try:
