@@ -4,13 +4,15 @@
 Metric (BASELINE.json): 8x8 blocks/s at q=3 niter=3 on a synthetic 8192x8192 luma
 plane, inputs resident in HBM.  A "step" is one pass of the hot path over one BATCH of
 synthetic input: `--batch` (default 12) independent 8192x8192 planes, each taken through
-a complete do_quantsmooth -- niter x {IDCT-to-plane kernel, [halo exchange], recovery
-kernel}, final clamp fused into the last recovery launch.  The planes of a step travel
+a complete do_quantsmooth -- the IDCT-to-plane kernel once, then niter x {[halo exchange],
+recovery kernel}: every recovery launch but the last also writes the next iteration's pixel
+planes (pass A fused into pass B); final clamp fused into the last launch.  The planes of a step travel
 together as one plane set: one launch per pass covers all of them (the job layer's
 qs_hip_idct_planes / qs_hip_smooth_planes), at every N.  (20 driver steps of 12 planes cover
 about a second, i.e. the power-capped steady state; `value` counts blocks.)
 
-  python bench.py [--gpus N --steps K --warmup W]
+  python bench.py [--gpus N --steps K --warmup W]      (N > 1 without a launcher: re-executes itself under
+                                                        torch.distributed.run, one rank per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: every plane is split into N contiguous block-row bands (strong scaling, total
@@ -44,6 +46,8 @@ of thread counts on a bounded sample of the same workload on this box's host cor
 Extra legs of the luma workload (not part of `value`; `--no-extras` skips them):
   single_plane_ms / value_batch1   ONE plane per step instead of twelve: single-image latency (N = 1) and single-image
                                    strong scaling (N > 1: the RCCL halo exchange is paid per plane)
+  scaling_emulation                N = 1: one rank's share of a SINGLE-image run on 2 / 4 / 8 GPUs emulated on this GPU (the
+                                   middle 1/N band of one plane, halo rows as device copies): ms per step, pass-B launch time, speed-up
   smooth_input                     N = 1: the same workload on the smooth variant of the image (periods x10, no noise),
                                    where the wave-uniform need_refresh skip applies
   product_route                    the PRODUCT's own multi-GPU route over the same N devices -- qs_hip_do_quantsmooth_sharded
