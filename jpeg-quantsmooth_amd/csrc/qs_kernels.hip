@@ -156,6 +156,31 @@ __device__ __forceinline__ float pix_from_byte(uint32_t v, int n) {
 //   rep_top / rep_bot : write the y = -1 / y = h apron rows by replication
 //             (false for the interior edges of a multi-GPU band, whose apron
 //             rows are halo rows received from the neighbouring band)
+// one pixel row of a block (8 clamped pixels o[]) into the plane at org (the block's pixel (0, 0)), plus the parts of the
+// clamp-to-edge apron that row owns: the columns x = -1 / x = w of edge blocks, and the replicated rows y = -1 / y = h
+__device__ __forceinline__ void
+store_pixel_row(uint8_t* __restrict__ org, int pitch, int y, const int (&o)[8], int bx, int by, int wblk, int hblk,
+                int rep_top, int rep_bot) {
+  uint2 pk;
+  pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+  pk.y = (uint32_t)o[4] | ((uint32_t)o[5] << 8) | ((uint32_t)o[6] << 16) | ((uint32_t)o[7] << 24);
+  uint8_t* rp = org + (size_t)y * pitch;
+  *reinterpret_cast<uint2*>(rp) = pk;
+  const bool top = (y == 0 && by == 0 && rep_top), bot = (y == 7 && by == hblk - 1 && rep_bot);
+  if (bx == 0) {
+    rp[-1] = (uint8_t)o[0];
+    if (top) rp[-1 - pitch] = (uint8_t)o[0];
+    if (bot) rp[-1 + pitch] = (uint8_t)o[0];
+  }
+  if (bx == wblk - 1) {
+    rp[8] = (uint8_t)o[7];
+    if (top) rp[8 - pitch] = (uint8_t)o[7];
+    if (bot) rp[8 + pitch] = (uint8_t)o[7];
+  }
+  if (top) *reinterpret_cast<uint2*>(rp - pitch) = pk;
+  if (bot) *reinterpret_cast<uint2*>(rp + pitch) = pk;
+}
+
 // 64 coefficients in registers (ws, natural order, sign-extended) -> the block's 64 pixels in the plane, plus the
 // parts of the clamp-to-edge apron this block owns.  Shared by pass A and by the fused epilogue of pass B.
 __device__ __forceinline__ void
@@ -170,37 +195,14 @@ idct_ws_to_plane(uint32_t (&ws)[64], uint8_t* __restrict__ plane, int wblk, int 
 #pragma unroll
     for (int j = 0; j < 8; ++j) row[j] = ws[y * 8 + j];
     idct_pass2_row(row, o);
-    uint2 pk;
-    pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
-    pk.y = (uint32_t)o[4] | ((uint32_t)o[5] << 8) | ((uint32_t)o[6] << 16) | ((uint32_t)o[7] << 24);
-    uint8_t* rp = org + (size_t)y * pitch;
-    *reinterpret_cast<uint2*>(rp) = pk;
-    const bool top = (y == 0 && by == 0 && rep_top), bot = (y == 7 && by == hblk - 1 && rep_bot);
-    if (bx == 0) {
-      rp[-1] = (uint8_t)o[0];
-      if (top) rp[-1 - pitch] = (uint8_t)o[0];
-      if (bot) rp[-1 + pitch] = (uint8_t)o[0];
-    }
-    if (bx == wblk - 1) {
-      rp[8] = (uint8_t)o[7];
-      if (top) rp[8 - pitch] = (uint8_t)o[7];
-      if (bot) rp[8 + pitch] = (uint8_t)o[7];
-    }
-    if (top) *reinterpret_cast<uint2*>(rp - pitch) = pk;
-    if (bot) *reinterpret_cast<uint2*>(rp + pitch) = pk;
+    store_pixel_row(org, pitch, y, o, bx, by, wblk, hblk, rep_top, rep_bot);
   }
 }
 
-// how: QS_IDCT_FIRST = iteration 0 (dequantise + range check); QS_IDCT_CLAMP = store the coefficients back clamped to
-// +-1023 (reference :2680-2686) while the pixels come from the UNCLAMPED values -- the order of the reference, whose
-// clamp sits behind the refresh pass (used behind the small-plane kernel when the clamp would otherwise have ridden on
-// a pass B whose fused epilogue writes the refresh); plane == nullptr: no pixels wanted (clamp only)
-enum { QS_IDCT_FIRST = 1, QS_IDCT_NEXT = 2, QS_IDCT_CLAMP = 4 };
 __device__ __forceinline__ void
 idct_block_to_plane(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
                     uint8_t* __restrict__ plane, int wblk, int hblk, int pitch,
-                    int how, int rep_top, int rep_bot, int* __restrict__ status, int blk) {
-  const int first = how & QS_IDCT_FIRST;
+                    int first, int rep_top, int rep_bot, int* __restrict__ status, int blk) {
   uint4* cp = reinterpret_cast<uint4*>(coef) + (size_t)blk * 8;
   uint32_t ws[64];
 #pragma unroll
@@ -212,17 +214,7 @@ idct_block_to_plane(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef
       ws[j * 8 + c * 2] = (uint32_t)(int32_t)(int16_t)(d[c] & 0xffff);
       ws[j * 8 + c * 2 + 1] = (uint32_t)((int32_t)d[c] >> 16);
     }
-    if (how & QS_IDCT_CLAMP) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        int lo = (int32_t)ws[j * 8 + c * 2], hi = (int32_t)ws[j * 8 + c * 2 + 1];
-        lo = min(max(lo, -1023), 1023); hi = min(max(hi, -1023), 1023);
-        d[c] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
-      }
-      cp[j] = make_uint4(d[0], d[1], d[2], d[3]);
-    }
   }
-  if (!plane) return;
   if (first) {
     int bad = 0;
 #pragma unroll
@@ -247,28 +239,24 @@ idct_block_to_plane(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef
 __global__ void __launch_bounds__(256)
 qs_idct_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
                      uint8_t* __restrict__ plane, int wblk, int hblk, int pitch,
-                     int how, int rep_top, int rep_bot, int* __restrict__ status, int blk_begin, int blk_end) {
-  const int blk = blk_begin + blockIdx.x * 256 + threadIdx.x;
-  if (blk >= blk_end) return;
-  idct_block_to_plane(cst, coef, plane, wblk, hblk, pitch, how, rep_top, rep_bot, status, blk);
+                     int first, int rep_top, int rep_bot, int* __restrict__ status) {
+  const int blk = blockIdx.x * 256 + threadIdx.x;
+  if (blk >= wblk * hblk) return;
+  idct_block_to_plane(cst, coef, plane, wblk, hblk, pitch, first, rep_top, rep_bot, status, blk);
 }
 
 #include "qs_devfn.h"
 
-// pass A over a set of planes (whole planes, or bands whose halo-side apron rows are left alone).
-// how: QS_IDCT_FIRST | QS_IDCT_NEXT (write QsPlaneRef::plane_next instead of ::plane: the stand-alone form of pass
-// B's fused epilogue, used behind the small-plane kernel) | QS_IDCT_CLAMP
+// pass A over a set of planes (whole planes, or bands whose halo-side apron rows are left alone)
 __global__ void __launch_bounds__(256)
-qs_idct_set_kernel(const QsPlaneSet set, int how) {
+qs_idct_set_kernel(const QsPlaneSet set, int first) {
   const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (w >= set.wave0[set.n]) return;
   const int i = qs_set_find(set, w);
   const QsPlaneRef& r = set.ref[i];
   const int blk = (w - set.wave0[i]) * 64 + (threadIdx.x & 63);
   if (blk >= r.wblk * r.hblk) return;
-  uint8_t* dst = (how & QS_IDCT_NEXT) ? r.plane_next : r.plane;
-  if (!dst && !(how & QS_IDCT_CLAMP)) return;             // (a plane of the set without a next plane)
-  idct_block_to_plane(r.cst, r.coef, dst, r.wblk, r.hblk, r.pitch, how,
+  idct_block_to_plane(r.cst, r.coef, r.plane, r.wblk, r.hblk, r.pitch, first,
                       r.mode & QS_PLANE_REP_TOP, r.mode & QS_PLANE_REP_BOT, r.status, blk);
 }
 
@@ -461,7 +449,7 @@ void qs_launch_idct_plane(const QsConsts* cst, int16_t* coef, uint8_t* plane, in
                           int first, int rep_top, int rep_bot, int* status, hipStream_t s) {
   const int nblk = wblk * hblk;
   hipLaunchKernelGGL(qs_idct_plane_kernel, dim3((nblk + 255) / 256), dim3(256), 0, s,
-                     cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), first ? QS_IDCT_FIRST : 0, rep_top, rep_bot, status, 0, nblk);
+                     cst, coef, plane, wblk, hblk, qs_plane_pitch(wblk), first, rep_top, rep_bot, status);
 }
 
 // Which form of pass B a launch of `groups` 64-block groups gets.  Measured on MI355X
@@ -489,30 +477,23 @@ static int qs_dp_waves(int groups) {
   return groups <= lim ? QS_DP_WAVES : groups <= lim2 ? 2 : 0;
 }
 
-// plane_next: the pixel plane of the next iteration (null: none), written by the kernel's fused epilogue -- or, behind
-// the small-plane kernel (whose waves share a block: no lane holds a whole one), by a pass-A launch over the same blocks
+// plane_next: the pixel plane of the next iteration (null: none), written by the kernel's fused epilogue (both forms of pass B)
 void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* plane, uint8_t* plane_next, int rep_top, int rep_bot,
                             int wblk, int hblk, int diag, int rebalance, int final_clamp, int blk_begin, int blk_end, hipStream_t s) {
   const int n = blk_end - blk_begin;
   if (n <= 0) return;
   const int pitch = qs_plane_pitch(wblk);
+  const int rep = (rep_top ? QS_PLANE_REP_TOP : 0) | (rep_bot ? QS_PLANE_REP_BOT : 0);
   if (const int nw = qs_dp_waves((n + 63) / 64)) {
     const dim3 g((n + 63) / 64), b(64 * nw);
-    // (with a next plane the clamp moves into the pass-A launch behind the kernel: that launch must see the unclamped
-    //  coefficients, the order of the reference, whose clamp sits behind its refresh pass)
-    const int clamp_b = plane_next ? 0 : final_clamp;
-#define QS_GO_DP(D, W) hipLaunchKernelGGL((qs_smooth_dp_kernel<D, W>), g, b, 0, s, cst, coef, plane, wblk, hblk, pitch, rebalance, clamp_b, blk_begin, blk_end)
+#define QS_GO_DP(D, W) hipLaunchKernelGGL((qs_smooth_dp_kernel<D, W>), g, b, 0, s, cst, coef, plane, plane_next, rep, wblk, hblk, pitch, rebalance, final_clamp, blk_begin, blk_end)
     if (nw == 2) { if (diag) QS_GO_DP(true, 2); else QS_GO_DP(false, 2); }
     else if (diag) QS_GO_DP(true, QS_DP_WAVES); else QS_GO_DP(false, QS_DP_WAVES);
 #undef QS_GO_DP
-    if (plane_next)
-      hipLaunchKernelGGL(qs_idct_plane_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
-                         cst, coef, plane_next, wblk, hblk, pitch, final_clamp ? QS_IDCT_CLAMP : 0, rep_top, rep_bot, (int*)nullptr, blk_begin, blk_end);
     return;
   }
   const int per_wg = 64 * QS_WAVES_PER_WG;
   const dim3 grid((n + per_wg - 1) / per_wg), block(per_wg);
-  const int rep = (rep_top ? QS_PLANE_REP_TOP : 0) | (rep_bot ? QS_PLANE_REP_BOT : 0);
 #define QS_GO(K) hipLaunchKernelGGL(K, grid, block, 0, s, cst, coef, plane, plane_next, rep, wblk, hblk, pitch, rebalance, final_clamp, blk_begin, blk_end)
   if (diag) QS_GO(qs_smooth_plane_kernel<true>); else QS_GO(qs_smooth_plane_kernel<false>);
 #undef QS_GO
@@ -521,24 +502,19 @@ void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* p
 void qs_launch_idct_set(const QsPlaneSet& set, int first, hipStream_t s) {
   const int nw = set.wave0[set.n];
   if (nw <= 0) return;
-  hipLaunchKernelGGL(qs_idct_set_kernel, dim3((nw + 3) / 4), dim3(256), 0, s, set, first ? QS_IDCT_FIRST : 0);
+  hipLaunchKernelGGL(qs_idct_set_kernel, dim3((nw + 3) / 4), dim3(256), 0, s, set, first);
 }
 
-// planes whose QsPlaneRef::plane_next is set get the next iteration's pixel plane written (see qs_launch_smooth_plane)
+// planes whose QsPlaneRef::plane_next is set get the next iteration's pixel plane written by the same launch
 void qs_launch_smooth_set(const QsPlaneSet& set, int diag, int final_clamp, hipStream_t s) {
   const int nw = set.wave0[set.n];
   if (nw <= 0) return;
   if (const int dw = qs_dp_waves(nw)) {
     const dim3 g(nw), b(64 * dw);
-    bool any_next = false;
-    for (int i = 0; i < set.n; ++i) any_next = any_next || set.ref[i].plane_next;
-    const int clamp_b = any_next ? 0 : final_clamp;           // (see qs_launch_smooth_plane)
-#define QS_GO_DP(D, W) hipLaunchKernelGGL((qs_smooth_dp_set_kernel<D, W>), g, b, 0, s, set, clamp_b)
+#define QS_GO_DP(D, W) hipLaunchKernelGGL((qs_smooth_dp_set_kernel<D, W>), g, b, 0, s, set, final_clamp)
     if (dw == 2) { if (diag) QS_GO_DP(true, 2); else QS_GO_DP(false, 2); }
     else if (diag) QS_GO_DP(true, QS_DP_WAVES); else QS_GO_DP(false, QS_DP_WAVES);
 #undef QS_GO_DP
-    if (any_next)
-      hipLaunchKernelGGL(qs_idct_set_kernel, dim3((nw + 3) / 4), dim3(256), 0, s, set, QS_IDCT_NEXT | (final_clamp ? QS_IDCT_CLAMP : 0));
     return;
   }
   const dim3 grid((nw + QS_WAVES_PER_WG - 1) / QS_WAVES_PER_WG), block(64 * QS_WAVES_PER_WG);

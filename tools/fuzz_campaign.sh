@@ -1,6 +1,6 @@
 #!/bin/bash
 # the 20,000-trial corpus (seed 77, tools/fuzz_gpu.py gen on the build box) replayed in every form of pass B and on the sharded / general routes
-O=gpurun_out/r03_fuzz; mkdir -p $O
+O=gpurun_out/${FUZZ_TAG:-r04_fuzz}; mkdir -p $O
 F=build/fuzz_r03_20k.jsonl
 run() { name=$1; shift; ( time env "$@" python tools/fuzz_gpu.py run $F ) > $O/fuzz_$name.txt 2>&1; tail -4 $O/fuzz_$name.txt | head -2; }
 run default X=1
