@@ -79,14 +79,8 @@ static void partition(const qs_hip_job* const* jobs, const std::vector<int>& whi
       for (int ci = 0; ci < job->ncomp; ++ci) {
         const int wb = job->wblk[ci], hb = job->hblk[ci];
         const int bands = std::max(1, (int)(((size_t)wb * hb + kBandBlocks - 1) / kBandBlocks));
-        // QS_HIP_BAND_TAPER=d (measurement): the first and the last band are 1/d of the plane, the others share the rest
-        static const int taper = [] { const char* v = getenv("QS_HIP_BAND_TAPER"); return v ? atoi(v) : 0; }();
-        std::vector<int> cut(1, 0);
-        if (taper >= 2 && bands >= 3 && hb / taper >= 8 * niter) {
-          const int t = hb / taper, mid = hb - 2 * t;
-          for (int k = 0; k < bands - 2; ++k) cut.push_back(t + (int)((long long)mid * k / (bands - 2)));
-          cut.push_back(hb - t);
-        } else {
+        std::vector<int> cut(1, 0);                         // band k = block rows [cut[k], cut[k + 1]): equal bands
+        {                                                    // (a small first and last band was measured: slower, profiles/r04c_route)
           const int rows = (hb + bands - 1) / bands;
           for (int r = rows; r < hb; r += rows) cut.push_back(r);
         }

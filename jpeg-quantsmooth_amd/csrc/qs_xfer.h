@@ -248,10 +248,7 @@ inline bool pinned_return(void* p) {
   return true;                                     // (b's destructor returns the block to the pool)
 }
 
-inline const size_t kStageMin = (size_t)1 << 20;
-// staging chunk: the unit whose DMA is queued as soon as its host copy is complete (QS_HIP_STAGE_CHUNK_MIB: measurement)
-inline const size_t kStageChunk = [] { const char* v = getenv("QS_HIP_STAGE_CHUNK_MIB"); const int n = v ? atoi(v) : 0;
-                                       return (size_t)(n >= 1 && n <= 64 ? n : 8) << 20; }();
+inline const size_t kStageMin = (size_t)1 << 20, kStageChunk = (size_t)8 << 20;
 inline const int kStageThreads = 4;   // parts per chunk
 inline const int kPoolThreads = 8;    // helper threads (several transfers can be in flight)
 
