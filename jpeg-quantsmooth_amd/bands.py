@@ -263,6 +263,20 @@ def run_bands_batched_sets(hip, engines, topo: BandTopology, niter: int, exchang
                 e.plane, e.plane2 = e.plane2, e.plane
 
 
+def run_bands_batched_fused(engines, topo: BandTopology, niter: int, exchange_many) -> None:
+    """The fused schedule for ANY engine that offers `smooth_next(final_clamp, write_next, rep_top, rep_bot)` (pass B that
+    also writes the next iteration's pixel plane into the engine's second plane and swaps the two): pass A once, then
+    niter x {ONE halo exchange for the planes the coming pass B reads, pass B of every plane}.  One launch per plane and
+    pass (run_bands_batched_sets is the one-launch-per-pass form for HipBandEngine); the CPU engine of the tests runs the
+    same loop under gloo."""
+    for e in engines:
+        e.idct(True, topo.rep_top, topo.rep_bot)
+    for it in range(niter):
+        exchange_many()
+        for e in engines:
+            e.smooth_next(it == niter - 1, it < niter - 1, topo.rep_top, topo.rep_bot)
+
+
 def exchange_halo_local(engines) -> None:
     """the same exchange between N logical bands living in one process
     (device-to-device copies): used to test the band logic on a single GPU"""
@@ -356,6 +370,15 @@ class HipBandEngine(BandEngine):
     def smooth(self, final_clamp):
         self.hip.smooth_plane(self.cst.data_ptr(), self.coef.data_ptr(), self.plane.data_ptr(),
                               self.wblk, self.hblk, self.flags, self.luma, final_clamp, self._s())
+
+    def smooth_next(self, final_clamp, write_next, rep_top=1, rep_bot=1):
+        """pass B; write_next: it also writes the next iteration's pixel plane (fused pass A) into plane2, and the two swap"""
+        if not write_next:
+            return self.smooth(final_clamp)
+        self.ensure_plane2()
+        self.hip.smooth_plane_next(self.cst.data_ptr(), self.coef.data_ptr(), self.plane.data_ptr(), self.plane2.data_ptr(),
+                                   self.wblk, self.hblk, self.flags, self.luma, final_clamp, rep_top, rep_bot, self._s())
+        self.plane, self.plane2 = self.plane2, self.plane
 
     def smooth_rows(self, row0, row1, final_clamp):
         if row1 > row0:

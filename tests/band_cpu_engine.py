@@ -46,6 +46,17 @@ class OracleBandEngine:
         f(self.coef.ctypes.data, self.wblk, self.hblk, self.quant.ctypes.data,
           self.plane.data_ptr(), self.pitch, APRON_X, self.flags, self.luma, int(final_clamp), row0, row1)
 
+    def smooth_next(self, final_clamp, write_next, rep_top=1, rep_bot=1):
+        """the fused form of the product engine, restated with two oracle calls: pass B, then pass A of the next
+        iteration into the SECOND plane (unclamped coefficients: the clamp comes last), and the planes swap"""
+        self.smooth(False if write_next else final_clamp)
+        if write_next:
+            if getattr(self, "plane2", None) is None:
+                self.plane2 = torch.zeros_like(self.plane)
+            self.plane, self.plane2 = self.plane2, self.plane
+            self.idct(False, rep_top, rep_bot)
+            assert not final_clamp, "the tests' fused loop clamps on the last iteration only, which writes no next plane"
+
     def row(self, y):
         o = self._row_off(y)
         return self.plane[o:o + self.pitch]

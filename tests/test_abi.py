@@ -21,6 +21,28 @@ def test_header_symbols_all_exported(pkg, hip):
         assert getattr(hip.lib, name) is not None
 
 
+def test_struct_layouts_match_the_header(tmp_path):
+    """the ctypes mirrors of qs_hip_job and qs_hip_plane_ref against what a C compiler makes of include/jpegqs_hip.h:
+    size and the offset of every field (a C program that includes the header prints them)"""
+    import ctypes as C
+    import subprocess
+    from jpeg_quantsmooth_amd import hipqs
+    fields = {"qs_hip_job": [f[0] for f in hipqs.Job._fields_], "qs_hip_plane_ref": [f[0] for f in hipqs.PlaneRef._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "jpegqs_hip.h"', 'int main(void) {']
+    for st, fs in fields.items():
+        src.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        for f in fs:
+            src.append(f'  printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    src += ['  return 0;', '}']
+    (tmp_path / "layout.c").write_text("\n".join(src))
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), "-o", str(tmp_path / "layout"), str(tmp_path / "layout.c")], check=True)
+    out = dict(line.split() for line in subprocess.run([str(tmp_path / "layout")], capture_output=True, text=True, check=True).stdout.splitlines())
+    for st, cls in (("qs_hip_job", hipqs.Job), ("qs_hip_plane_ref", hipqs.PlaneRef)):
+        assert int(out[st]) == C.sizeof(cls), (st, out[st], C.sizeof(cls))
+        for f in fields[st]:
+            assert int(out[f"{st}.{f}"]) == getattr(cls, f).offset, (st, f)
+
+
 def test_flag_values_match_reference_api(pkg):
     F = pkg.FLAGS
     # reference libjpegqs.h:14-32

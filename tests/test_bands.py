@@ -104,7 +104,16 @@ def _batched_worker(rank, world, port, tmp, packed=False):
         assert coef.shape[:2] == (25, 17)
         engs.append(OracleBandEngine(Oracle(), hip, coef[r0:r1].copy(), quant, 1, plane=planes2d[n] if packed else None))
     topo = bands.BandTopology(rank, world, r0, r1)
-    if packed:        # the exchange bench.py uses: one packed send + receive per neighbour for the whole batch
+    if packed == "fused":   # bench.py's schedule: pass A once, then per iteration one packed exchange of the CURRENT planes + pass B
+        planes2d_b = torch.zeros_like(planes2d)
+        for n, e in enumerate(engs):
+            e.plane2 = planes2d_b[n]
+
+        def exch():
+            cur = planes2d if engs[0].plane.data_ptr() == planes2d[0].data_ptr() else planes2d_b
+            bands.exchange_halo_packed(hip, cur, 17, r1 - r0, topo, dist)
+        bands.run_bands_batched_fused(engs, topo, 3, exch)
+    elif packed:      # the exchange bench.py uses: one packed send + receive per neighbour for the whole batch
         bands.run_bands_batched(engs, topo, 3, lambda: bands.exchange_halo_packed(hip, planes2d, 17, r1 - r0, topo, dist))
     else:
         bands.run_bands_batched(engs, topo, 3, lambda: bands.exchange_halo_dist_many(engs, topo, dist))
@@ -114,7 +123,7 @@ def _batched_worker(rank, world, port, tmp, packed=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("packed", [False, True, "fused"])
 def test_batched_bands_gloo_equal_unsharded(packed, oracle, synth, tmp_path):
     """the schedule bench.py uses for N > 1: the planes of a batch advance together, ONE batched
     halo exchange per iteration for all of them -- per-plane messages, or (bench.py) the rows of the
@@ -270,6 +279,38 @@ def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
         assert pr.get("error") is None, pr
         assert pr["entry"] == "qs_hip_do_quantsmooth_sharded" and pr["devices"] == [0, 0]
         assert pr["equals_one_device_result"] is True and pr["verify_ok"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbands", [2, 5])
+@pytest.mark.parametrize("size", [(264, 328), (2048, 1536)])
+def test_fused_bands_on_one_gpu_equal_unsharded(gpu, pkg, oracle, synth, nbands, size):
+    """the FUSED band schedule (pass A once; every pass B but the last writes the next iteration's plane, halo rows are
+    exchanged on whichever plane is current) with N logical bands on one device: per-plane launches
+    (qs_hip_smooth_plane_next through HipBandEngine.smooth_next; the small size takes the small-plane kernel, the large
+    one the one-block-per-lane kernel) -- bit-exact against the unsharded oracle"""
+    import torch
+    from jpeg_quantsmooth_amd import bands
+    coef, quant = synth.synth_gray(size[0], size[1], 50, seed=4)
+    hblk = coef.shape[0]
+    dev = torch.device("cuda:0")
+    niter = 3
+    for flags in (0, 1):
+        engines, topos = [], []
+        for r in range(nbands):
+            r0, r1 = bands.band_rows(hblk, nbands, r)
+            topos.append(bands.BandTopology(r, nbands, r0, r1))
+            engines.append(bands.HipBandEngine(gpu, torch, torch.from_numpy(coef[r0:r1].copy()).to(dev), quant, flags))
+        for e, t in zip(engines, topos):
+            e.idct(True, t.rep_top, t.rep_bot)
+        for it in range(niter):
+            bands.exchange_halo_local(engines)                     # rows of the engines' CURRENT planes
+            for e, t in zip(engines, topos):
+                e.smooth_next(it == niter - 1, it < niter - 1, t.rep_top, t.rep_bot)
+        torch.cuda.synchronize()
+        got = np.concatenate([e.coef.cpu().numpy() for e in engines], axis=0)
+        want = oracle.do_quantsmooth([coef], [quant], flags, niter, threads=8)["coefs"][0]
+        assert np.array_equal(got, want), f"flags={flags}"
 
 
 @pytest.mark.gpu
