@@ -283,12 +283,12 @@ def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nbands", [2, 5])
-@pytest.mark.parametrize("size", [(264, 328), (2048, 1536)])
+@pytest.mark.parametrize("size", [(264, 328), (4096, 4096)])
 def test_fused_bands_on_one_gpu_equal_unsharded(gpu, pkg, oracle, synth, nbands, size):
     """the FUSED band schedule (pass A once; every pass B but the last writes the next iteration's plane, halo rows are
     exchanged on whichever plane is current) with N logical bands on one device: per-plane launches
-    (qs_hip_smooth_plane_next through HipBandEngine.smooth_next; the small size takes the small-plane kernel, the large
-    one the one-block-per-lane kernel) -- bit-exact against the unsharded oracle"""
+    (qs_hip_smooth_plane_next through HipBandEngine.smooth_next; the small-plane kernel except for the two 131 k-block
+    bands of the 4096^2 plane, which take the one-block-per-lane kernel) -- bit-exact against the unsharded oracle"""
     import torch
     from jpeg_quantsmooth_amd import bands
     coef, quant = synth.synth_gray(size[0], size[1], 50, seed=4)
