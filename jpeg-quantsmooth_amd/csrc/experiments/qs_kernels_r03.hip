@@ -727,8 +727,21 @@ static int qs_dp_waves(int groups) {
   return groups <= lim ? QS_DP_WAVES : groups <= lim2 ? 2 : 0;
 }
 
-void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* plane, int wblk, int hblk,
-                            int diag, int rebalance, int final_clamp, int blk_begin, int blk_end, hipStream_t s) {
+// (round 4: the product's launchers take the NEXT iteration's pixel plane -- the shipped kernels write it themselves.
+//  These round-3 kernels do not: the launchers here keep the interface alive for the variant builds with the unfused
+//  order -- pass B without the clamp, a stand-alone pass A into the next plane, then the clamp.  Whole planes only.)
+static void qs_r03_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* plane, int wblk, int hblk,
+                                int diag, int rebalance, int final_clamp, int blk_begin, int blk_end, hipStream_t s);
+void qs_launch_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* plane, uint8_t* plane_next, int rep_top, int rep_bot,
+                            int wblk, int hblk, int diag, int rebalance, int final_clamp, int blk_begin, int blk_end, hipStream_t s) {
+  if (!plane_next) { qs_r03_smooth_plane(cst, coef, plane, wblk, hblk, diag, rebalance, final_clamp, blk_begin, blk_end, s); return; }
+  if (blk_begin != 0 || blk_end != wblk * hblk) abort();     // (the experiments build has no partial-range pass A)
+  qs_r03_smooth_plane(cst, coef, plane, wblk, hblk, diag, rebalance, 0, blk_begin, blk_end, s);
+  qs_launch_idct_plane(cst, coef, plane_next, wblk, hblk, 0, rep_top, rep_bot, nullptr, s);
+  if (final_clamp) qs_launch_clamp(coef, (size_t)wblk * hblk, s);
+}
+static void qs_r03_smooth_plane(const QsConsts* cst, int16_t* coef, const uint8_t* plane, int wblk, int hblk,
+                                int diag, int rebalance, int final_clamp, int blk_begin, int blk_end, hipStream_t s) {
   const int n = blk_end - blk_begin;
   if (n <= 0) return;
   if (const int nw = qs_dp_waves((n + 63) / 64)) {
@@ -764,7 +777,20 @@ void qs_launch_idct_set(const QsPlaneSet& set, int first, hipStream_t s) {
   hipLaunchKernelGGL(qs_idct_set_kernel, dim3((nw + 3) / 4), dim3(256), 0, s, set, first);
 }
 
+static void qs_r03_smooth_set(const QsPlaneSet& set, int diag, int final_clamp, hipStream_t s);
 void qs_launch_smooth_set(const QsPlaneSet& set, int diag, int final_clamp, hipStream_t s) {
+  bool any_next = false;
+  for (int i = 0; i < set.n; ++i) any_next = any_next || set.ref[i].plane_next;
+  if (!any_next) { qs_r03_smooth_set(set, diag, final_clamp, s); return; }
+  qs_r03_smooth_set(set, diag, 0, s);                        // unfused order: pass B, pass A into the next planes, clamp
+  for (int i = 0; i < set.n; ++i) {
+    const QsPlaneRef& r = set.ref[i];
+    if (r.plane_next)
+      qs_launch_idct_plane(r.cst, r.coef, r.plane_next, r.wblk, r.hblk, 0, r.mode & QS_PLANE_REP_TOP, r.mode & QS_PLANE_REP_BOT, nullptr, s);
+    if (final_clamp) qs_launch_clamp(r.coef, (size_t)r.wblk * r.hblk, s);
+  }
+}
+static void qs_r03_smooth_set(const QsPlaneSet& set, int diag, int final_clamp, hipStream_t s) {
   const int nw = set.wave0[set.n];
   if (nw <= 0) return;
   if (const int dw = qs_dp_waves(nw)) {

@@ -43,6 +43,26 @@ def test_struct_layouts_match_the_header(tmp_path):
             assert int(out[f"{st}.{f}"]) == getattr(cls, f).offset, (st, f)
 
 
+def test_experiments_translation_unit_still_builds(tmp_path):
+    """csrc/experiments/ (round-3 kernel variants, built only by tools/build_variants.sh) must keep compiling against the
+    product's headers and keep defining every launcher csrc/qs_launch.h declares for qs_kernels.hip -- otherwise a variant
+    library links with holes and fails only on the GPU box"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("no hipcc")
+    csrc = ROOT / "jpeg-quantsmooth_amd" / "csrc"
+    obj = tmp_path / "exp.o"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
+                    "-Wno-unused-function", f"-I{csrc}", "-c", str(csrc / "experiments" / "qs_kernels_r03.hip"), "-o", str(obj)],
+                   check=True, capture_output=True, timeout=900)
+    have = subprocess.run(["nm", "-C", "--defined-only", str(obj)], capture_output=True, text=True, check=True).stdout
+    ship = subprocess.run(["nm", "-C", "--defined-only", str(csrc / "qs_kernels.o")], capture_output=True, text=True, check=True).stdout
+    sig = lambda text: {line.split(" T ", 1)[1] for line in text.splitlines() if " T qs_launch_" in line}
+    assert sig(ship) and sig(ship) <= sig(have), sig(ship) - sig(have)
+
+
 def test_flag_values_match_reference_api(pkg):
     F = pkg.FLAGS
     # reference libjpegqs.h:14-32
