@@ -102,35 +102,91 @@ __device__ __forceinline__ void store_block(int16_t* coef, size_t blk, const int
 }
 
 // FDCT + round + clamp into each coefficient's interval (reference :551-561)
-__device__ __forceinline__ void fdct_clamp(float (&f)[64], int (&c)[64], const QsConsts* __restrict__ cst) {
+// (QS_OPAQUE_ROW: the quantiser scalars are indexed through an opaque per-row offset, so that their scalar loads stay
+//  next to their use, 24 at a time; with compile-time indices hipcc hoists all 192 of a block to the top of the kernel
+//  and spills them into VGPR lanes / AGPRs -- 385 spilled SGPRs and one wave per SIMD in the kernels below)
+//  TOK: a value the previous row produced -- the row offset is "computed" only after it, which keeps the scheduler
+//  from lining all eight offsets, and behind them all 192 invariant loads, up at the top anyway)
+#define QS_OPAQUE_ROW(N0, G, TOK) int N0 = (G) * 8; asm volatile("" : "+s"(N0), "+v"(TOK))
+template <class CP>
+__device__ __forceinline__ void fdct_clamp(float (&f)[64], int (&c)[64], CP cst) {
   fdct2d(f);
+  int tok = 0;
 #pragma unroll
-  for (int n = 0; n < 64; ++n) {
-    int orig, lo, hi;
-    interval(c[n], cst->qn[n], cst->x1n[n], cst->x2n[n], orig, lo, hi);
-    int v = f2i_x86(round_half_away(f[n]));
-    c[n] = min(max(v, lo), hi);
+  for (int g = 0; g < 8; ++g) {
+    QS_OPAQUE_ROW(n0, g, tok);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int orig, lo, hi;
+      interval(c[g * 8 + k], cst->qn[n0 + k], cst->x1n[n0 + k], cst->x2n[n0 + k], orig, lo, hi);
+      int v = f2i_x86(round_half_away(f[g * 8 + k]));
+      c[g * 8 + k] = min(max(v, lo), hi);
+    }
+    tok = c[g * 8 + 7];
+  }
+}
+
+// fdct_clamp for a block whose coefficients are still in memory: they stream through eight at a time (one 16-byte
+// line: load, clamp the eight FDCT values into their intervals, store), so the 64 coefficients never occupy registers
+// next to the 64 floats -- the predictor kernels then fit 128 VGPRs (four waves per SIMD instead of two)
+template <class CP>
+__device__ __forceinline__ void fdct_clamp_stream(float (&f)[64], int16_t* __restrict__ coef, size_t blk, CP cst) {
+  fdct2d(f);
+  uint32_t tok = 0;
+  uint4* p = reinterpret_cast<uint4*>(coef) + blk * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    QS_OPAQUE_ROW(n0, j, tok);
+    const uint4 v = p[j];
+    uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int c2[2] = {(int16_t)(d[k] & 0xffff), (int32_t)d[k] >> 16};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int n = n0 + k * 2 + h;
+        int orig, lo, hi;
+        interval(c2[h], cst->qn[n], cst->x1n[n], cst->x2n[n], orig, lo, hi);
+        const int r = f2i_x86(round_half_away(f[j * 8 + k * 2 + h]));
+        c2[h] = min(max(r, lo), hi);
+      }
+      d[k] = ((uint32_t)c2[0] & 0xffffu) | ((uint32_t)c2[1] << 16);
+    }
+    p[j] = make_uint4(d[0], d[1], d[2], d[3]);
+    tok = d[3];
   }
 }
 
 // rebalance on register-resident coefficients (reference :1823-1848)
-__device__ __forceinline__ void rebalance_regs(int (&c)[64], const QsConsts* __restrict__ cst) {
+template <class CP>
+__device__ __forceinline__ void rebalance_regs(int (&c)[64], CP cst) {
   long long m0 = 0, m1 = 0;
+  int tok = 0;
 #pragma unroll
-  for (int n = 1; n < 64; ++n) {
-    int orig, lo, hi;
-    interval(c[n], cst->qn[n], cst->x1n[n], cst->x2n[n], orig, lo, hi);
-    m0 += (long long)(c[n] * orig);
-    m1 += (long long)(orig * orig);
+  for (int g = 0; g < 8; ++g) {
+    QS_OPAQUE_ROW(n0, g, tok);
+#pragma unroll
+    for (int k = (g == 0 ? 1 : 0); k < 8; ++k) {
+      int orig, lo, hi;
+      interval(c[g * 8 + k], cst->qn[n0 + k], cst->x1n[n0 + k], cst->x2n[n0 + k], orig, lo, hi);
+      m0 += (long long)(c[g * 8 + k] * orig);
+      m1 += (long long)(orig * orig);
+    }
+    tok = (int)m1;
   }
   if (m1 > m0) {
     const int mul = (int)(((m1 << 13) + (m0 >> 1)) / m0);
 #pragma unroll
-    for (int n = 1; n < 64; ++n) {
-      int orig, lo, hi;
-      interval(c[n], cst->qn[n], cst->x1n[n], cst->x2n[n], orig, lo, hi);
-      const int v = (c[n] * mul + 0x1000) >> 13;
-      c[n] = min(max(v, lo), hi);
+    for (int g = 0; g < 8; ++g) {
+      QS_OPAQUE_ROW(n0, g, tok);
+#pragma unroll
+      for (int k = (g == 0 ? 1 : 0); k < 8; ++k) {
+        int orig, lo, hi;
+        interval(c[g * 8 + k], cst->qn[n0 + k], cst->x1n[n0 + k], cst->x2n[n0 + k], orig, lo, hi);
+        const int v = (c[g * 8 + k] * mul + 0x1000) >> 13;
+        c[g * 8 + k] = min(max(v, lo), hi);
+      }
+      tok = c[g * 8 + 7];
     }
   }
 }
@@ -171,20 +227,23 @@ __device__ __forceinline__ float regress(const int (&a0)[10], const int (&a1)[10
 // --------------------------------------------------------------------------
 // JOINT_YUV predictor: one chroma block per lane.  planeC = this component's
 // plane (pass A of this iteration), planeL = low-res luma; same geometry.
-__device__ __forceinline__ void joint_block(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
+template <class CP>
+__device__ __forceinline__ void joint_block(CP cst, int16_t* __restrict__ coef,
                                             const uint8_t* __restrict__ planeC, const uint8_t* __restrict__ planeL,
                                             int wblk, int pitch, int blk, int do_rebalance, int final_clamp) {
   const int by = blk / wblk, bx = blk - by * wblk;
   const size_t org = (size_t)(by * 8 + 1) * pitch + QS_APRON_X + bx * 8;
 
-  int c[64];
-  load_block(coef, blk, c);
   float f[64];
   int a0[10], a1[10], a2[10], b0[10], b1[10], b2[10];
   load_row10(planeL + org - pitch, a0); load_row10(planeC + org - pitch, b0);
   load_row10(planeL + org, a1);         load_row10(planeC + org, b1);
 #pragma unroll
   for (int y = 0; y < 8; ++y) {
+    // one pixel row at a time: left to itself hipcc issues the loads of all ten rows of both planes up front and
+    // keeps them (and their unpacked bytes) live -- 384 registers, one wave per SIMD, 105 of them spilled at a
+    // 256-register budget.  The barrier keeps a row's loads behind the previous row's arithmetic.
+    asm volatile("" ::: "memory");
     load_row10(planeL + org + (size_t)(y + 1) * pitch, a2);
     load_row10(planeC + org + (size_t)(y + 1) * pitch, b2);
 #pragma unroll
@@ -194,10 +253,18 @@ __device__ __forceinline__ void joint_block(const QsConsts* __restrict__ cst, in
       float a = ((float)(a1[x + 1] * 16 - sA) * scale + (float)sB) * 0.0625f;
       a = (a < 0 ? 0 : a) - 128.0f;
       f[y * 8 + x] = a > 128.0f ? 128.0f : a;
+      asm volatile("" : "+v"(f[y * 8 + x]));               // one pixel after the other (the 64 predictions are independent:
+                                                           //  interleaved, their temporaries cost hundreds of registers)
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) { a0[k] = a1[k]; a1[k] = a2[k]; b0[k] = b1[k]; b1[k] = b2[k]; }
   }
+  if (!do_rebalance && !final_clamp) {                       // (wave-uniform) the JOINT_YUV step in front of the recovery kernel
+    fdct_clamp_stream(f, coef, blk, cst);
+    return;
+  }
+  int c[64];                                                 // LOW_QUALITY chroma: the block ends here (reference :936)
+  load_block(coef, blk, c);
   fdct_clamp(f, c, cst);
   if (do_rebalance) rebalance_regs(c, cst);
   if (final_clamp) {
@@ -227,7 +294,15 @@ qs_joint_set_kernel(const QsPlaneSet set, const QsPlaneAux lowres, int do_rebala
   const QsPlaneRef& r = set.ref[i];
   const int blk = (w - set.wave0[i]) * 64 + (threadIdx.x & 63);
   if (blk >= r.wblk * r.hblk) return;
-  joint_block(r.cst, r.coef, r.plane, lowres.p[i], r.wblk, r.pitch, blk,
+  // The constants pointer is wave-uniform (every lane of a wave works on the same plane) but comes out of a dynamically
+  // indexed kernarg array: to hipcc it is a generic pointer of unknown uniformity, and the 192 quantiser values of
+  // fdct_clamp arrive through 186 per-lane flat_load_dwordx4 into as many VGPRs (505 registers, one wave per SIMD).
+  // readfirstlane states the uniformity and the constant address space the invariance: scalar loads again.
+  typedef const QsConsts __attribute__((address_space(4)))* QsConstsK;
+  const uint64_t cu = reinterpret_cast<uint64_t>(r.cst);
+  QsConstsK cst = (QsConstsK)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(cu >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cu));
+  joint_block(cst, r.coef, r.plane, lowres.p[i], r.wblk, r.pitch, blk,
               do_rebalance && (r.mode & QS_PLANE_REBALANCE), final_clamp);
 }
 
@@ -278,6 +353,7 @@ qs_lowq_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef,
 #undef QS_LQ
       if (an > 0.0f) a = f2i_x86((float)a - a0 / an);  // the reference keeps `a` as an int
       f[y * 8 + x] = (float)(a - 128);
+      asm volatile("" : "+v"(f[y * 8 + x]));               // one pixel after the other, as in joint_block
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) { r0[k] = r1[k]; r1[k] = r2[k]; }
