@@ -805,15 +805,15 @@ def run_colour(c):
     band = B.ColourBand(hip, torch, work[0][0], quants, hsamp, vsamp, (size, size), flags, args.niter, topo, dev)
     band.chroma_row0 = c0
     timing = [False]
-    plain_smooth = band.eng[0].smooth
+    plain_next = band.eng[0].smooth_next
 
-    def luma_smooth(final_clamp):                           # HIP events around the luma recovery launches
+    def luma_smooth_next(*a, **kw):                         # HIP events around the luma recovery launches
         if not timing[0]:
-            return plain_smooth(final_clamp)
+            return plain_next(*a, **kw)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(stream); plain_smooth(final_clamp); e1.record(stream)
+        e0.record(stream); plain_next(*a, **kw); e1.record(stream)
         ev_pairs.append((e0, e1))
-    band.eng[0].smooth = luma_smooth
+    band.eng[0].smooth_next = luma_smooth_next
 
     def one_image(cf, timed):
         for ci in range(3):

@@ -508,6 +508,15 @@ class ColourBand:
                                  self.lowres_plane().data_ptr(), e.wblk, e.hblk, 0, 0, s)
         e.smooth(last)
 
+    def pass_b_next(self, ci, final_clamp, write_next):
+        """pass B of the recovery route (not LOW_QUALITY) that also writes the next pass A's output (fused, see
+        HipBandEngine.smooth_next): the JOINT_YUV step first, on the plane this iteration reads"""
+        e = self.eng[ci]
+        if ci > 0 and self.joint:
+            self.hip.joint_plane(e.cst.data_ptr(), e.coef.data_ptr(), e.plane.data_ptr(),
+                                 self.lowres_plane().data_ptr(), e.wblk, e.hblk, 0, 0, self._s())
+        e.smooth_next(final_clamp, write_next, self.topo.rep_top, self.topo.rep_bot)
+
     def clamp(self, ci):
         e = self.eng[ci]
         self.hip.clamp_plane(e.coef.data_ptr(), e.wblk, e.hblk, self._s())
@@ -543,6 +552,8 @@ def run_colour_bands(bands, exchange) -> None:
     b0 = bands[0]
     niter, need_lowres = b0.niter, True
     extra_y = 1
+    if niter > 0 and not b0.lowq:
+        return _run_colour_bands_fused(bands, exchange)
     # ---- luma: iterations + the extra refresh that feeds the chroma passes
     for it in range(niter + extra_y):
         for b in bands:
@@ -577,6 +588,41 @@ def run_colour_bands(bands, exchange) -> None:
             for b in bands:
                 b.clamp(ci)
         if b0.upsample:
+            for b in bands:
+                b.upsample_chroma(ci, b.chroma_row0)
+
+
+def _run_colour_bands_fused(bands, exchange) -> None:
+    """run_colour_bands with pass A fused into pass B (niter >= 1, recovery route): pass A once per component; every pass B
+    writes the plane the NEXT stage reads -- the next iteration's, or the refresh the chroma stages / the upsampling read
+    -- and the +-1023 clamp rides on the last one (the fused IDCT sees the unclamped coefficients, reference :2668-2689).
+    Halo rows are exchanged on the engines' current planes, at the same points of the schedule as in the unfused loop."""
+    b0 = bands[0]
+    niter = b0.niter
+    # ---- luma: niter iterations; the last one writes the refresh that feeds the chroma passes
+    for b in bands:
+        b.pass_a(0, True)
+    for it in range(niter):
+        exchange([b.planes_for_halo(0) for b in bands])
+        for b in bands:
+            b.pass_b_next(0, it == niter - 1, True)
+    if b0.L is None:
+        exchange([b.planes_for_halo(0) for b in bands])        # 1x1 luma: L is this (refreshed) plane, its aprons are read
+    else:
+        for b in bands:
+            b.downsample()
+        exchange([b.planes_for_halo("L") for b in bands])
+    # ---- chroma
+    for ci in (1, 2):
+        extra = bool(b0.upsample)
+        for b in bands:
+            b.pass_a(ci, True)
+        for it in range(niter):
+            exchange([b.planes_for_halo(ci) for b in bands])
+            for b in bands:
+                b.pass_b_next(ci, it == niter - 1, it < niter - 1 or extra)
+        if extra:
+            exchange([b.planes_for_halo(ci) for b in bands])    # the refreshed plane's halo: the upsampling's 3x3 windows
             for b in bands:
                 b.upsample_chroma(ci, b.chroma_row0)
 
