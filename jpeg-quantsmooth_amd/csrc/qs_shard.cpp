@@ -432,18 +432,63 @@ static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::
   }
   const double t_up = wall_ms();
 
+  // ref(B, ci).plane is the component's CURRENT pixel plane everywhere below; with the fused schedule ref.plane_next is
+  // its second plane (stage_band allocates two per component) and the two swap after every pass B that wrote it
   auto plane_of = [&](int ci) {
     return [&bands, ci](int d, int, uint8_t** p, int* wb, int* hb) {
       const BandPlane& P = bands.b[d].planes[ci];
-      *p = bands.b[d].px.as<uint8_t>() + P.px_off; *wb = P.wb; *hb = P.hb;
+      *p = bands.b[d].set.ref[ci].plane; *wb = P.wb; *hb = P.hb;
       return true;
     };
   };
   auto ref = [](Band& B, int ci) -> QsPlaneRef& { return B.set.ref[ci]; };
   auto lowres = [&](Band& B) -> uint8_t* { return sub ? B.aux[0].as<uint8_t>() : ref(B, 0).plane; };
+  // Fused schedule (recovery route, niter >= 1; the twin of bands.py: _run_colour_bands_fused): pass A once per
+  // component; every pass B writes the plane the next stage reads -- the next iteration's, or the refresh the chroma
+  // stages / the upsampling read -- and the +-1023 clamp rides on the last one (the fused IDCT sees the unclamped
+  // coefficients, reference :2668-2689).  LOW_QUALITY and niter = 0 keep the unfused order below.
+  const bool fuse = !lowq && niter > 0;
+  for (Band& B : bands.b)
+    for (int ci = 0; ci < 3; ++ci) ref(B, ci).plane_next = ref(B, ci).plane + plane_stride(B.planes[ci].wb, B.planes[ci].hb);
+  // component ci of every band: one fused pass B (JOINT_YUV step first); write_next: it also writes the second plane
+  auto fused_pass_b = [&](int ci, int final_clamp, bool write_next) -> int {
+    for (size_t d = 0; d < bands.b.size(); ++d) {
+      Band& B = bands.b[d];
+      HIP_TRY(hipSetDevice(B.dev));
+      const BandPlane& P = B.planes[ci];
+      // (the plane about to be written is the one the neighbours pulled their halo rows from one pass earlier)
+      if (write_next) if (int r = before_overwrite(bands, d)) return r;
+      if (ci && joint) qs_launch_joint(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, lowres(B), P.wb, P.hb, 0, 0, B.s);
+      qs_launch_smooth_plane(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, write_next ? ref(B, ci).plane_next : nullptr,
+                             !P.halo_top, !P.halo_bot, P.wb, P.hb, diag, comp_rebalance(job, ci, flags), final_clamp,
+                             0, P.wb * P.hb, B.s);
+      if (write_next) std::swap(ref(B, ci).plane, ref(B, ci).plane_next);
+    }
+    return QS_HIP_OK;
+  };
+  auto first_pass_a = [&](int ci) -> int {
+    for (size_t d = 0; d < bands.b.size(); ++d) {
+      Band& B = bands.b[d];
+      HIP_TRY(hipSetDevice(B.dev));
+      if (int r = before_overwrite(bands, d)) return r;
+      const BandPlane& P = B.planes[ci];
+      qs_launch_idct_plane(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, P.wb, P.hb, 1,
+                           !P.halo_top, !P.halo_bot, ref(B, ci).status, B.s);
+    }
+    return QS_HIP_OK;
+  };
 
   // ---- luma: niter iterations + the refresh pass that feeds the chroma stages
-  for (int it = 0; it <= niter; ++it) {
+  if (fuse) {
+    if (int r = first_pass_a(0)) return r;
+    for (int it = 0; it < niter; ++it) {
+      if (int r = exchange(bands, 1, plane_of(0))) return r;
+      if (int r = fused_pass_b(0, it == niter - 1, true)) return r;
+    }
+    // the refresh of a subsampled luma only feeds the downsample, which stays inside the band
+    if (!sub) if (int r = exchange(bands, 1, plane_of(0))) return r;
+  }
+  for (int it = 0; !fuse && it <= niter; ++it) {
     for (size_t d = 0; d < bands.b.size(); ++d) {
       Band& B = bands.b[d];
       HIP_TRY(hipSetDevice(B.dev));
@@ -472,7 +517,7 @@ static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::
   for (Band& B : bands.b) {
     HIP_TRY(hipSetDevice(B.dev));
     const BandPlane& P = B.planes[0];
-    qs_launch_clamp(ref(B, 0).coef, (size_t)P.wb * P.hb, B.s);
+    if (!fuse) qs_launch_clamp(ref(B, 0).coef, (size_t)P.wb * P.hb, B.s);
     if (sub)
       qs_launch_downsample(ref(B, 0).plane, P.wb, P.hb, B.aux[0].as<uint8_t>(), B.planes[1].wb, B.planes[1].hb, ws, hs, B.s);
   }
@@ -487,7 +532,15 @@ static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::
   const size_t up_pitch = qs_hip_upsample_pitch(job->image_width, ws);
   for (int ci = 1; ci <= 2; ++ci) {
     const int extra = upsample ? 1 : 0;
-    for (int it = 0; it < niter + extra; ++it) {
+    if (fuse) {
+      if (int r = first_pass_a(ci)) return r;
+      for (int it = 0; it < niter; ++it) {
+        if (int r = exchange(bands, 1, plane_of(ci))) return r;
+        if (int r = fused_pass_b(ci, it == niter - 1, it < niter - 1 || extra)) return r;
+      }
+      if (extra) if (int r = exchange(bands, 1, plane_of(ci))) return r;   // the refreshed plane's halo: the upsampling's 3x3 windows
+    }
+    for (int it = 0; !fuse && it < niter + extra; ++it) {
       for (size_t d = 0; d < bands.b.size(); ++d) {
         Band& B = bands.b[d];
         HIP_TRY(hipSetDevice(B.dev));
@@ -513,7 +566,7 @@ static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::
         }
       }
     }
-    if (extra)                                               // as for luma: clamp after the refresh
+    if (extra && !fuse)                                      // as for luma: clamp after the refresh
       for (Band& B : bands.b) {
         HIP_TRY(hipSetDevice(B.dev));
         qs_launch_clamp(ref(B, ci).coef, (size_t)B.planes[ci].wb * B.planes[ci].hb, B.s);
