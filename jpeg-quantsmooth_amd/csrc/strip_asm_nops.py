@@ -21,7 +21,7 @@ Everything else -- no-ops next to compiler-generated code, after empty (register
 longer waits -- stays.  The result is what the assembler would have produced had the two statements
 been written as one.
 
-usage: strip_asm_nops.py <in.s> <out.s>     prints the count; exit status 1 if nothing matched
+usage: strip_asm_nops.py <in.s> <out.s>     prints the counts (a compiler that stops inserting the no-ops is not an error)
 """
 import sys
 
@@ -58,7 +58,7 @@ def main(src_path, dst_path):
         i += 1
     open(dst_path, "w").write("\n".join(out))
     print(f"strip_asm_nops: {removed} no-ops between two asm statements removed, {kept} after an asm statement kept")
-    return 0 if removed else 1
+    return 0
 
 
 if __name__ == "__main__":
