@@ -261,16 +261,19 @@ def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
            "--size", "1024", "--steps", "2", "--warmup", "1", "--verify", "--no-cpu-baseline", *extra]
-    # (the "--backend nccl" case: two ranks on one device is something RCCL refuses, which exercises the
-    # labelled fall-back to host-staged halo rows -- the path a multi-GPU node without working RCCL would take)
+    # (the "--backend nccl" case: two ranks on one device is something RCCL refuses.  A run that asked for RCCL must then
+    # END, non-zero and without a result line -- a host-staged gloo number must never look like an RCCL result)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    if "nccl" in extra:
+        assert r.returncode != 0, r.stdout[-2000:]
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout[-2000:]
+        assert "RCCL did not come up" in r.stderr and "--backend gloo" in r.stderr, r.stderr[-2000:]
+        return
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["verify_band_edges_ok"] is True and d["verify_ok"] is True
-    if "nccl" in extra:
-        assert "RCCL unavailable" in d["config"]["comm_note"] and "gloo" in d["config"]["sharding"]
     if not extra:
         # the extra legs: single-plane steps over the same bands, and the product's own route
         # (qs_hip_do_quantsmooth_sharded over two logical devices) run as a child process of rank 0

@@ -20,6 +20,10 @@ def _tool():
 TERM = "\t;;#ASMSTART\n\tv_mul_f32 v140, v140, v141\n\tv_add_f32 v8, v8, v140\n\t;;#ASMEND\n"
 PIN = "\t;;#ASMSTART\n\t;;#ASMEND\n"
 PARTIAL = "\t;;#ASMSTART\n\tv_cvt_pkrtz_f16_f32 v3, v1, v2\n\t;;#ASMEND\n"
+# the small-plane kernel's optional term: scalar compare-and-branch around the VALU body, the statement ends in a label
+OPT = "\t;;#ASMSTART\n\ts_cmp_lg_u32 s4, 0\n\ts_cbranch_scc1 1f\n\tv_sub_f32 v1, v2, v3\n\tv_add_f32 v8, v8, v1\n1:\n\t;;#ASMEND\n"
+# a partial-register write in the MIDDLE of a statement whose last instruction is on the list
+MIDDLE = "\t;;#ASMSTART\n\tv_cvt_pkrtz_f16_f32 v3, v1, v2\n\tv_add_f32 v8, v8, v140\n\t;;#ASMEND\n"
 
 
 @pytest.mark.parametrize("text,removed,kept", [
@@ -29,6 +33,8 @@ PARTIAL = "\t;;#ASMSTART\n\tv_cvt_pkrtz_f16_f32 v3, v1, v2\n\t;;#ASMEND\n"
     (PARTIAL + "\ts_nop 0\n" + TERM, 0, 1),                               # last instruction not on the list: stays
     (TERM + "\ts_nop 1\n" + TERM, 0, 0),                                  # a longer wait is not this hazard: untouched
     (TERM + "\ts_nop 0\n" + TERM + "\ts_nop 0\n" + PIN + "\ts_nop 0\n" + TERM, 2, 1),
+    (OPT + "\ts_nop 0\n" + TERM, 1, 0),                                   # branchy statement, every instruction on the list: goes
+    (MIDDLE + "\ts_nop 0\n" + TERM, 0, 1),                                # any instruction off the list: stays
 ])
 def test_strip_only_between_two_term_statements(tmp_path, text, removed, kept, capsys):
     src, dst = tmp_path / "in.s", tmp_path / "out.s"
@@ -40,6 +46,18 @@ def test_strip_only_between_two_term_statements(tmp_path, text, removed, kept, c
     out = dst.read_text()
     assert out.count("s_nop") == text.count("s_nop") - removed
     assert [l for l in out.split("\n") if "s_nop" not in l] == [l for l in text.split("\n") if "s_nop" not in l]
+
+
+def test_strip_floor_fails_loudly(tmp_path, capsys):
+    """csrc/Makefile passes --min-removed for the shipped translation unit: an assembly printer that no longer marks the
+    asm statements (nothing found to strip) must fail the build, not ship slower kernels silently"""
+    src, dst = tmp_path / "in.s", tmp_path / "out.s"
+    src.write_text(TERM + "\ts_nop 0\n" + TERM)
+    assert _tool().main(str(src), str(dst), 1) == 0
+    assert _tool().main(str(src), str(dst), 2) == 1
+    assert "expected at least 2" in capsys.readouterr().err
+    mk = (CSRC / "Makefile").read_text()
+    assert "STRIP_FLOOR" in mk and "build_stripped.sh" in mk
 
 
 def test_shipped_library_was_built_through_the_strip(tmp_path):
