@@ -149,6 +149,11 @@ void qs_hip_release_cache(void);
 
 int qs_hip_device_count(void);
 const char *qs_hip_last_error(void);
+/* Version of this interface: bumped whenever a struct layout or the meaning of an argument changes (5: round 5 --
+ * qs_hip_plane_ref back to its 48-byte form, second planes through qs_hip_smooth_planes_next).  A caller built against
+ * this header can compare QS_HIP_ABI_VERSION with what the loaded library reports. */
+#define QS_HIP_ABI_VERSION 5
+int qs_hip_abi_version(void);
 
 /* bytes of the per-component constant block; pixel-plane pitch and size */
 size_t qs_hip_consts_bytes(void);
@@ -199,11 +204,16 @@ typedef struct {
 	int32_t wblk, hblk, luma;
 	int32_t band;  /* 0: a whole plane.  Bit 0 / bit 1: the plane is a band of block rows whose top /
 	                * bottom apron row is a halo row received from the neighbouring band (pass A leaves it alone) */
-	uint8_t *d_plane_next;  /* qs_hip_smooth_planes: NULL, or the second plane the next iteration's pixels go to
-	                         * (see qs_hip_smooth_plane_next); ignored by qs_hip_idct_planes */
-} qs_hip_plane_ref;
+} qs_hip_plane_ref;   /* 48 bytes, unchanged since the plane-set calls appeared: every field must be set by the caller */
 int qs_hip_idct_planes(const qs_hip_plane_ref *refs, int n, int first, void *stream);
 int qs_hip_smooth_planes(const qs_hip_plane_ref *refs, int n, int flags, int final_clamp, void *stream);
+/* qs_hip_smooth_planes that ALSO writes the next iteration's pixel planes (see qs_hip_smooth_plane_next):
+ * d_plane_next[i] is the second plane of refs[i] -- same geometry, a different buffer -- or NULL for a plane that gets
+ * none; d_plane_next == NULL is qs_hip_smooth_planes.  The second planes travel in a PARALLEL array on purpose: the
+ * struct above keeps its size and stride, so callers compiled against an earlier header (who neither zero nor know a
+ * trailing field) stay correct. */
+int qs_hip_smooth_planes_next(const qs_hip_plane_ref *refs, uint8_t *const *d_plane_next, int n, int flags,
+		int final_clamp, void *stream);
 
 /* JOINT_YUV chroma predictor + fdct_clamp for one chroma plane (reference :577-579,
  * 893-921, 343-347, 551-561); d_luma_lowres = luma at this plane's resolution and

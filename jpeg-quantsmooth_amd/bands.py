@@ -235,7 +235,7 @@ def run_bands_batched_sets(hip, engines, topo: BandTopology, niter: int, exchang
     (DESIGN.md 4.2b table); twelve bands in one launch fill it.  HipBandEngine objects only.
 
     fused (default): pass A runs ONCE; every pass B but the last writes the next iteration's pixel planes itself
-    (qs_hip_plane_ref::d_plane_next) into each engine's second plane, and the engines' `plane` / `plane2` swap --
+    (the parallel d_plane_next[] array of qs_hip_smooth_planes_next) into each engine's second plane, and the engines' `plane` / `plane2` swap --
     `engine.plane` (and `engine.row()`) is always the plane the coming pass B reads, which is what
     `exchange_many()` must exchange the halo rows of.  Per iteration: [halo rows], ONE launch."""
     band = (1 if topo.up is not None else 0) | (2 if topo.down is not None else 0)

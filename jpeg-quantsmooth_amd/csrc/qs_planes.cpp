@@ -95,7 +95,7 @@ extern "C" int qs_hip_smooth_rows(const void* d_consts, int16_t* d_coef, const u
   return smooth_rows(d_consts, d_coef, d_plane, wblk, hblk, row0, row1, flags, luma, final_clamp, stream, "qs_hip_smooth_rows");
 }
 
-static int build_plane_set(const qs_hip_plane_ref* refs, int n, int flags, QsPlaneSet& set, const char* who) {
+static int build_plane_set(const qs_hip_plane_ref* refs, uint8_t* const* next, int n, int flags, QsPlaneSet& set, const char* who) {
   if (!refs || n < 1 || n > QS_MAX_PLANES) return qs_fail(QS_HIP_EINVAL, "%s: 1..%d planes per launch", who, QS_MAX_PLANES);
   memset(&set, 0, sizeof set);
   set.n = n;
@@ -109,8 +109,8 @@ static int build_plane_set(const qs_hip_plane_ref* refs, int n, int flags, QsPla
     QsPlaneRef& R = set.ref[i];
     R.cst = static_cast<const QsConsts*>(r.d_consts);
     R.coef = r.d_coef; R.plane = r.d_plane; R.status = r.d_status;
-    R.plane_next = r.d_plane_next;
-    if (r.d_plane_next && r.d_plane_next == r.d_plane)
+    R.plane_next = next ? next[i] : nullptr;
+    if (R.plane_next && R.plane_next == r.d_plane)
       return qs_fail(QS_HIP_EINVAL, "%s: d_plane_next must be a different buffer (other blocks still read d_plane)", who);
     R.wblk = r.wblk; R.hblk = r.hblk; R.pitch = qs_plane_pitch(r.wblk);
     R.mode = ((!(flags & QS_NO_REBALANCE) && (r.luma || !(flags & QS_NO_REBALANCE_UV))) ? QS_PLANE_REBALANCE : 0) |
@@ -122,7 +122,7 @@ static int build_plane_set(const qs_hip_plane_ref* refs, int n, int flags, QsPla
 
 extern "C" int qs_hip_idct_planes(const qs_hip_plane_ref* refs, int n, int first, void* stream) {
   QsPlaneSet set;
-  if (int r = build_plane_set(refs, n, 0, set, "qs_hip_idct_planes")) return r;
+  if (int r = build_plane_set(refs, nullptr, n, 0, set, "qs_hip_idct_planes")) return r;
   if (first)
     for (int i = 0; i < n; ++i)
       if (!refs[i].d_status) return qs_fail(QS_HIP_EINVAL, "qs_hip_idct_planes: first pass needs d_status");
@@ -130,14 +130,26 @@ extern "C" int qs_hip_idct_planes(const qs_hip_plane_ref* refs, int n, int first
   return launch_status("qs_hip_idct_planes");
 }
 
-extern "C" int qs_hip_smooth_planes(const qs_hip_plane_ref* refs, int n, int flags, int final_clamp, void* stream) {
+static int smooth_planes(const qs_hip_plane_ref* refs, uint8_t* const* next, int n, int flags, int final_clamp, void* stream, const char* who) {
   if (flags & (QS_JOINT_YUV | QS_UPSAMPLE_UV | QS_LOW_QUALITY))
-    return qs_fail(QS_HIP_ENOTSUP, "qs_hip_smooth_planes: flags 0x%x need the cross-component stages", flags);
+    return qs_fail(QS_HIP_ENOTSUP, "%s: flags 0x%x need the cross-component stages", who, flags);
   QsPlaneSet set;
-  if (int r = build_plane_set(refs, n, flags, set, "qs_hip_smooth_planes")) return r;
+  if (int r = build_plane_set(refs, next, n, flags, set, who)) return r;
   qs_launch_smooth_set(set, (flags & QS_DIAGONALS) != 0, final_clamp, static_cast<hipStream_t>(stream));
-  return launch_status("qs_hip_smooth_planes");
+  return launch_status(who);
 }
+
+extern "C" int qs_hip_smooth_planes(const qs_hip_plane_ref* refs, int n, int flags, int final_clamp, void* stream) {
+  return smooth_planes(refs, nullptr, n, flags, final_clamp, stream, "qs_hip_smooth_planes");
+}
+
+// the second planes come in a parallel array: qs_hip_plane_ref keeps its size and stride
+extern "C" int qs_hip_smooth_planes_next(const qs_hip_plane_ref* refs, uint8_t* const* d_plane_next, int n, int flags,
+                                         int final_clamp, void* stream) {
+  return smooth_planes(refs, d_plane_next, n, flags, final_clamp, stream, "qs_hip_smooth_planes_next");
+}
+
+extern "C" int qs_hip_abi_version(void) { return QS_HIP_ABI_VERSION; }
 
 extern "C" int qs_hip_clamp_plane(int16_t* d_coef, int wblk, int hblk, void* stream) {
   if (int r = check_plane_args(d_coef, d_coef, wblk, hblk, "qs_hip_clamp_plane")) return r;

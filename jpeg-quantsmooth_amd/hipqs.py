@@ -63,8 +63,20 @@ class Job(C.Structure):
 class PlaneRef(C.Structure):
     """qs_hip_plane_ref: one plane of a plane-set launch (device pointers)"""
     _fields_ = [("d_consts", C.c_void_p), ("d_coef", C.c_void_p), ("d_plane", C.c_void_p), ("d_status", C.c_void_p),
-                ("wblk", C.c_int32), ("hblk", C.c_int32), ("luma", C.c_int32), ("band", C.c_int32),
-                ("d_plane_next", C.c_void_p)]
+                ("wblk", C.c_int32), ("hblk", C.c_int32), ("luma", C.c_int32), ("band", C.c_int32)]
+
+
+class PlaneRefs:
+    """what HipQS.plane_refs() returns: the qs_hip_plane_ref array of a plane-set launch plus the PARALLEL array of second
+    planes qs_hip_smooth_planes_next takes (None when no plane has one)"""
+    def __init__(self, arr, nxt):
+        self.arr, self.next = arr, nxt
+
+    def __len__(self):
+        return len(self.arr)
+
+    def __getitem__(self, i):
+        return self.arr[i]
 
 
 MAX_PLANES = 56
@@ -101,6 +113,8 @@ ABI = {
                                      C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_idct_planes": (C.c_int, [C.POINTER(PlaneRef), C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_smooth_planes": (C.c_int, [C.POINTER(PlaneRef), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_smooth_planes_next": (C.c_int, [C.POINTER(PlaneRef), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "qs_hip_abi_version": (C.c_int, []),
     "qs_hip_joint_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_lowq_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -302,23 +316,30 @@ class HipQS:
 
     @staticmethod
     def plane_refs(planes):
-        """[(d_consts, d_coef, d_plane, d_status, wblk, hblk, luma[, band[, d_plane_next]])] -> ctypes array for the
+        """[(d_consts, d_coef, d_plane, d_status, wblk, hblk, luma[, band[, d_plane_next]])] -> PlaneRefs for the
         *_planes calls; band: bit 0 / bit 1 = the top / bottom apron row is a halo row (a band of a sharded plane);
-        d_plane_next: the plane qs_hip_smooth_planes writes the next iteration's pixels into (None: none)"""
+        d_plane_next: the plane the smoothing launch writes the next iteration's pixels into (None: none) -- these go
+        into the parallel array of qs_hip_smooth_planes_next, the struct itself has no such field"""
         arr = (PlaneRef * len(planes))()
-        for r, p in zip(arr, planes):
+        nxt = (C.c_void_p * len(planes))()
+        any_next = False
+        for i, (r, p) in enumerate(zip(arr, planes)):
             cst, coef, plane, status, wb, hb, luma = p[:7]
             r.d_consts, r.d_coef, r.d_plane, r.d_status = cst, coef, plane, status
             r.wblk, r.hblk, r.luma = wb, hb, int(luma)
             r.band = int(p[7]) if len(p) > 7 else 0
-            r.d_plane_next = p[8] if len(p) > 8 else None
-        return arr
+            nxt[i] = p[8] if len(p) > 8 else None
+            any_next = any_next or bool(nxt[i])
+        return PlaneRefs(arr, nxt if any_next else None)
 
     def idct_planes(self, refs, first, stream=None):
-        self._check(self.lib.qs_hip_idct_planes(refs, len(refs), int(first), stream))
+        self._check(self.lib.qs_hip_idct_planes(refs.arr, len(refs), int(first), stream))
 
     def smooth_planes(self, refs, flags, final_clamp=0, stream=None):
-        self._check(self.lib.qs_hip_smooth_planes(refs, len(refs), flags, int(final_clamp), stream))
+        if refs.next is not None:
+            self._check(self.lib.qs_hip_smooth_planes_next(refs.arr, refs.next, len(refs), flags, int(final_clamp), stream))
+        else:
+            self._check(self.lib.qs_hip_smooth_planes(refs.arr, len(refs), flags, int(final_clamp), stream))
 
     def smooth_rows(self, d_consts, d_coef, d_plane, wblk, hblk, row0, row1, flags, luma=1, final_clamp=0, stream=None):
         self._check(self.lib.qs_hip_smooth_rows(d_consts, d_coef, d_plane, wblk, hblk, row0, row1, flags,

@@ -43,6 +43,25 @@ def test_struct_layouts_match_the_header(tmp_path):
             assert int(out[f"{st}.{f}"]) == getattr(cls, f).offset, (st, f)
 
 
+def test_plane_ref_keeps_its_original_size_and_abi_version():
+    """qs_hip_plane_ref is 48 bytes, as in every header since the plane-set calls appeared (a trailing
+    d_plane_next field changed the array stride under callers that never zeroed it -- the second planes now travel in
+    the parallel array of qs_hip_smooth_planes_next); the library reports the header's ABI version"""
+    import ctypes as C
+    import re
+    from jpeg_quantsmooth_amd import hipqs
+    assert C.sizeof(hipqs.PlaneRef) == 48
+    assert [f[0] for f in hipqs.PlaneRef._fields_] == ["d_consts", "d_coef", "d_plane", "d_status", "wblk", "hblk", "luma", "band"]
+    hdr = (ROOT / "include" / "jpegqs_hip.h").read_text()
+    ver = int(re.search(r"#define QS_HIP_ABI_VERSION (\d+)", hdr).group(1))
+    hip = hipqs.HipQS.__new__(hipqs.HipQS)
+    lib = hipqs.load_library()
+    assert lib.qs_hip_abi_version() == ver >= 5
+    refs = hipqs.HipQS.plane_refs([(1, 2, 3, 4, 5, 6, 1), (1, 2, 3, 4, 5, 6, 0, 2, 99)])
+    assert len(refs) == 2 and refs.next is not None and refs.next[0] is None and refs.next[1] == 99 and refs[1].band == 2
+    assert hipqs.HipQS.plane_refs([(1, 2, 3, 4, 5, 6, 1)]).next is None
+
+
 def test_experiments_translation_unit_still_builds(tmp_path):
     """csrc/experiments/ (round-3 kernel variants, built only by tools/build_variants.sh) must keep compiling against the
     product's headers and keep defining every launcher csrc/qs_launch.h declares for qs_kernels.hip -- otherwise a variant
