@@ -1,0 +1,126 @@
+"""First contact with more than one GPU (Next 3): the three steps of tools/first_contact.sh as tests.
+
+Nothing in this repository has run on two devices: the development box and the driver's GPU test box have one.  These
+tests make a multi-GPU `pytest -m gpu` exercise the real transports by itself:
+  (a) the peer-copy + cross-device event protocol of csrc/qs_shard.cpp alone (tools/first_contact_p2p),
+  (b) qs_hip_do_quantsmooth_sharded over real devices, every block against the compiled reference,
+  (c) bench.py --gpus N over RCCL, band edges verified, `rccl_ranks == N`.
+With fewer than two devices the N >= 2 cases SKIP (reported with -rs); each step's degenerate N = 1 form runs
+everywhere, so the scripts themselves cannot rot.
+"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+def _ndev(gpu):
+    return gpu.device_count()
+
+
+def _counts(gpu):
+    n, out = 2, []
+    while n <= _ndev(gpu):
+        out.append(n)
+        n *= 2
+    return out
+
+
+def _p2p_binary():
+    exe = ROOT / "tools" / "first_contact_p2p"
+    if not exe.exists():
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", str(ROOT / "tools" / "first_contact_p2p.hip"), "-o", str(exe)],
+                       check=True, timeout=600)
+    return exe
+
+
+def _run_p2p(n):
+    r = subprocess.run([str(_p2p_binary()), str(n), "32"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "first_contact_p2p: PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "row ring: 0 wrong words" in r.stdout and "bulk ring: 0 wrong sampled words" in r.stdout
+    return r.stdout
+
+
+def test_multigpu_p2p_ring_degenerate_one_device(gpu):
+    """(a) at N = 1: the A / X event protocol with a device copying to itself"""
+    _run_p2p(1)
+
+
+def test_multigpu_p2p_ring_real_devices(gpu):
+    """(a): hipDeviceEnablePeerAccess + hipMemcpyPeerAsync on the receiver's stream behind the sender's event, for
+    every power-of-two device count the node has"""
+    if _ndev(gpu) < 2:
+        pytest.skip(f"needs >= 2 HIP devices, {_ndev(gpu)} visible")
+    for n in _counts(gpu):
+        print(_run_p2p(n))
+
+
+def _run_shard(devices, small):
+    cmd = [sys.executable, str(ROOT / "tools" / "first_contact_shard.py"), "--devices", ",".join(map(str, devices))]
+    if small:
+        cmd.append("--small")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1700, cwd=str(ROOT))
+    assert r.returncode == 0 and "first_contact_shard: PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count(": OK --") == 3, r.stdout[-3000:]
+    return r.stdout
+
+
+def test_multigpu_sharded_route_degenerate_one_device(gpu):
+    """(b) at N = 1 and reduced sizes: one band per configuration, no exchange; every block vs the reference"""
+    _run_shard([0], small=True)
+
+
+def test_multigpu_sharded_route_real_devices_every_block(gpu):
+    """(b): qs_hip_do_quantsmooth_sharded over devices 0..N-1 at FULL size (8192^2 q3, 16384^2 q3, 8192^2 4:2:0 q6 n5),
+    every block against oracle/_ref/libqsref_none.so and against the one-device result"""
+    if _ndev(gpu) < 2:
+        pytest.skip(f"needs >= 2 HIP devices, {_ndev(gpu)} visible")
+    n = _counts(gpu)[-1]
+    print(_run_shard(list(range(n)), small=False))
+    if n > 2:
+        print(_run_shard([0, 1], small=True))
+
+
+def _bench(extra, timeout=900):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *extra], capture_output=True, text=True, timeout=timeout, cwd=str(ROOT), env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_multigpu_bench_rccl_real_devices(gpu):
+    """(c): `python bench.py --gpus N` over RCCL (the default back end; it ENDS the run if RCCL does not come up):
+    band edges verified against the reference, rccl_ranks == N, single-image leg and the product's own route present;
+    then q6 (colour bands) at the largest count"""
+    if _ndev(gpu) < 2:
+        pytest.skip(f"needs >= 2 HIP devices, {_ndev(gpu)} visible")
+    for n in _counts(gpu):
+        d = _bench(["--gpus", str(n), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
+        assert d["n_gpus"] == n and d["config"]["rccl_ranks"] == n and d["scaling"] == "strong"
+        assert d["verify_ok"] is True and d["verify_band_edges_ok"] is True
+        assert d["value"] > 0 and d["value_batch1"] > 0
+        pr = d["product_route"]
+        assert pr.get("error") is None and pr["verify_ok"] is True and pr["devices"] == list(range(n)), pr
+        print(f"[info] N = {n}: value {d['value'] / 1e6:.1f} M blocks/s, batch 1 {d['value_batch1'] / 1e6:.1f}, product route {pr['ms_per_image']:.2f} ms")
+    n = _counts(gpu)[-1]
+    d = _bench(["--gpus", str(n), "--quality", "6", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["n_gpus"] == n and d["config"]["rccl_ranks"] == n and d["verify_ok"] is True
+
+
+def test_multigpu_first_contact_script_runs_on_this_box(gpu, tmp_path):
+    """the one-command script itself, on whatever this box has (N = 1: every step in its degenerate form) -- only the
+    cheap steps: (a), and a syntax check of the whole script; (b)-(d) are the tests above"""
+    subprocess.run(["bash", "-n", str(ROOT / "tools" / "first_contact.sh")], check=True)
+    text = (ROOT / "tools" / "first_contact.sh").read_text()
+    for piece in ("first_contact_p2p", "first_contact_shard.py", "bench.py --gpus", "tests/test_multigpu.py", "SUMMARY.txt"):
+        assert piece in text
