@@ -34,13 +34,20 @@ struct FGroup {
   Download down;                          // results on their way back
   hipStream_t s = nullptr;
   size_t blocks = 0, coef_bytes = 0;
+  // progress callback installed: one event behind every iteration's launch, and what an iteration of this group is
+  // worth in the reference's progress units (own block rows x v_samp; halo rows of a band are somebody else's work)
+  std::vector<hipEvent_t> it_ev;
+  long long units = 0;
   // QS_HIP_TRACE only: device timestamps "input is on the device" / "kernels done" / "results are in pinned host memory"
   hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
   float t_ms[3] = {0, 0, 0};              // ... in ms after the call's first event, read when the group is drained
   FGroup() = default;
   FGroup(const FGroup&) = delete;
   FGroup& operator=(const FGroup&) = delete;
-  ~FGroup() { for (hipEvent_t& e : tev) if (e) { (void)hipEventDestroy(e); e = nullptr; } }
+  ~FGroup() {
+    for (hipEvent_t& e : tev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (hipEvent_t& e : it_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  }
   // everything queued on the group's stream has completed: give the arenas back
   void release_transients(bool keep_stage) {
     coef.release(); px.release(); cst.release(); status.release();
@@ -127,7 +134,8 @@ void qsj::fused_stage_sizes(const qs_hip_job* job, int niter, std::vector<size_t
   }
 }
 
-int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int flags, int niter, int* results) {
+int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int flags, int niter, int* results, ProgressPlan* plan) {
+  if (plan && which.size() != 1) plan = nullptr;             // (progress is a single-job matter)
   StreamLease lease;
   if (!lease.p) return qs_fail(QS_HIP_ENODEV, "could not create HIP streams: %s", hipGetErrorString(hipGetLastError()));
   std::list<FGroup> groups;
@@ -219,7 +227,14 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
         set.ref[i].plane_next = it == niter - 1 ? nullptr : (it & 1) ? a : b;
       }
       qs_launch_smooth_set(set, diag, it == niter - 1, G.s);
+      if (plan) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        G.it_ev.push_back(e);
+        HIP_TRY(hipEventRecord(e, G.s));
+      }
     }
+    if (plan) for (const FPlane& P : G.planes) G.units += (long long)(P.keep1 - P.keep0) * jobs[P.job]->vsamp[P.ci];
     HIP_TRY(hipGetLastError());
     if (G.tev[1]) HIP_TRY(hipEventRecord(G.tev[1], G.s));
     // pinned: a pageable destination would make this call wait for the whole stream
@@ -243,7 +258,18 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
     host_pieces(jobs[P.job], P.ci, P.src_row0 + P.keep0, P.keep1 - P.keep0, P.coef_off + (size_t)P.keep0 * P.wb * 128, out);
   };
   std::vector<FGroup*> held;
+  long long units_done = 0;                                  // progress: completed group-iterations, in the reference's units
   auto drain_group = [&](FGroup& G) -> int {
+    // Progress (reference :2656-2664): every iteration of this group that has completed on the device counts; the
+    // calls whose share of the work is done are made now, in the reference's sequence.  A cancel is handled like a
+    // tripped range check: nothing more of the job is written, rows already written are restored, and the job is
+    // re-run in the reference's order with the recorded answers (below).
+    if (plan && !plan->cancelled)
+      for (hipEvent_t e : G.it_ev) {
+        HIP_TRY(hipEventSynchronize(e));
+        units_done += G.units;
+        if (plan->advance(units_done)) { for (int ji : G.jobs) bad_job[ji] = 1; break; }
+      }
     HIP_TRY(G.down.wait_first(G.s));
     const int32_t* hst = static_cast<const int32_t*>(G.hstatus.p);
     for (size_t i = 0; i < G.planes.size(); ++i) if (hst[i]) bad_job[G.planes[i].job] = 1;
@@ -271,6 +297,7 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
   auto pump = [&]() -> int {
     std::deque<FGroup*> inflight;
     for (FGroup& G : groups) {
+      if (plan && plan->cancelled) break;                    // cancelled: nothing further is started
       if (inflight.size() >= kWindow) {
         if (int r = drain_group(*inflight.front())) return r;
         inflight.pop_front();
@@ -326,8 +353,9 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
     if (scattered[ji]) restore_job(ji);                      // (otherwise the host input is still untouched)
   }
   if (trace_on()) {
-    fprintf(stderr, "qs_hip trace: fused  %zu job(s) in %zu group(s)  enqueue %.2f ms  drain+download %.2f ms  (%zu re-run)\n",
-            which.size(), groups.size(), t_enq - t_start, wall_ms() - t_enq, rerun.size());
+    fprintf(stderr, "qs_hip trace: fused  %zu job(s) in %zu group(s)  enqueue %.2f ms  drain+download %.2f ms  (%zu re-run)%s\n",
+            which.size(), groups.size(), t_enq - t_start, wall_ms() - t_enq, rerun.size(),
+            plan ? (plan->cancelled ? "  progress: cancelled by the callback" : "  progress: callback served from this route") : "");
     // device timeline per group, ms after the first group's stream work began: input on the device / kernels done / results in pinned memory
     fprintf(stderr, "qs_hip trace: fused  device timeline (upload done, kernels done, download done):");
     for (const FGroup& G : groups) fprintf(stderr, " [%.2f %.2f %.2f]", G.t_ms[0], G.t_ms[1], G.t_ms[2]);
@@ -342,6 +370,7 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
   groups.clear();                                            // give the arenas back before the re-runs allocate
   if (trace_on()) fprintf(stderr, "qs_hip trace: fused  release %.2f ms\n", wall_ms() - t_clear);
   for (int ji : rerun)
-    results[ji] = run_job(jobs[ji], flags, niter, 0, nullptr, nullptr, /*eager=*/false);
+    results[ji] = plan ? run_job(jobs[ji], flags, niter, plan->progprec, &ProgressPlan::replay, plan, /*eager=*/false)
+                       : run_job(jobs[ji], flags, niter, 0, nullptr, nullptr, /*eager=*/false);
   return QS_HIP_OK;
 }

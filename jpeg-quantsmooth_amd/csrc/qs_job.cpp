@@ -369,6 +369,49 @@ size_t qsj::env_size(const char* name, size_t dflt) {
   seen.emplace_back(name, read());
   return seen.back().second;
 }
+// ---- the reference's progress calls as a function of the geometry (see qs_jobint.h)
+void qsj::ProgressPlan::init(const qs_hip_job* job, int niter, int progprec_arg, qs_hip_progress_fn f, void* ud) {
+  fn = f; userdata = ud; progprec = progprec_arg;
+  calls.clear(); made = 0; cancelled = false; replayed = 0;
+  int prog_max = 0;
+  for (int ci = 0; ci < job->ncomp; ++ci) prog_max += job->hblk[ci] * job->vsamp[ci] * niter;   // reference :2474-2478
+  int pp = progprec_arg;
+  if (pp == 0) pp = 20;
+  if (pp < 0) pp = prog_max;
+  progprec_eff = pp;
+  if (prog_max <= 0 || pp <= 0) return;
+  int prog_thr = (int)((unsigned)(prog_max + pp - 1) / (unsigned)pp);
+  long long units = 0;
+  for (int ci = 0; ci < job->ncomp; ++ci)                  // every component of a plane-set job runs niter iterations
+    for (int it = 0; it < niter; ++it) {                   // reference :2656-2664
+      units += (long long)job->hblk[ci] * job->vsamp[ci];
+      int cur = (int)units;
+      if (cur >= prog_thr) {
+        cur = (int)((long long)pp * cur / prog_max);
+        prog_thr = (int)(((long long)(cur + 1) * prog_max + pp - 1) / pp);
+        calls.push_back({units, cur});
+      }
+    }
+}
+
+bool qsj::ProgressPlan::advance(long long units_done) {
+  while (!cancelled && made < calls.size() && calls[made].units <= units_done) {
+    const int stop = fn(userdata, calls[made].cur, progprec_eff);
+    ++made;
+    if (stop) cancelled = true;
+  }
+  return cancelled;
+}
+
+int qsj::ProgressPlan::replay(void* self, int cur, int max) {
+  ProgressPlan* P = static_cast<ProgressPlan*>(self);
+  if (P->replayed < P->made) {                              // already reported by the pipelined route: answer from the record
+    const size_t k = P->replayed++;
+    return (P->cancelled && k == P->made - 1) ? 1 : 0;
+  }
+  return P->fn(P->userdata, cur, max);                      // beyond the record: live
+}
+
 bool qsj::job_fusable(const qs_hip_job* job, int flags) {
   static const bool off = getenv("QS_HIP_NO_FUSE") != nullptr;
   if (off || (flags & QS_LOW_QUALITY) || job_needs_lowres(job, flags)) return false;
@@ -566,24 +609,33 @@ int qsj::do_quantsmooth_impl(qs_hip_job* job, int flags, int niter, int progprec
   if (qs_hip_device_count() <= 0)
     return qs_fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
 
-  if (!progress) {                                             // several GPUs and a job worth spreading over them
+  // A progress callback does not send the job to the slow route any more (missing 4): the plane-set
+  // routes report completed work through a ProgressPlan; only the coupled-colour routes (whose component order IS the
+  // reference's) keep the host-synchronised general route for callers that want progress.
+  ProgressPlan plan;
+  const bool fusable = job_fusable(job, flags);
+  if (progress && fusable) plan.init(job, niter, progprec, progress, userdata);
+  ProgressPlan* pl = (progress && fusable) ? &plan : nullptr;
+  auto careful = [&]() {                                       // the reference's own order; calls already made are not repeated
+    if (pl) return run_job(job, flags, niter, progprec, &ProgressPlan::replay, pl, /*eager=*/false);
+    return run_job(job, flags, niter, progprec, progress, userdata, /*eager=*/false);
+  };
+  if (!progress || fusable) {                                  // several GPUs and a job worth spreading over them
     const std::vector<int> devs = shard_devices_for(job, flags, niter);
-    if (!devs.empty()) {
-      int r = run_sharded(job, flags, niter, devs);
-      if (r == JOB_RERUN_CAREFUL)
-        r = run_job(job, flags, niter, progprec, progress, userdata, /*eager=*/false);
+    if (!devs.empty() && (!progress || fusable)) {
+      int r = run_sharded(job, flags, niter, devs, pl);
+      if (r == JOB_RERUN_CAREFUL) r = careful();
       return r;
     }
   }
-  if (!progress && job_fusable(job, flags)) {
+  if (fusable) {
     int result = QS_HIP_ENODEV;
     qs_hip_job* one[1] = { job };
-    if (int r = run_fused(one, std::vector<int>{0}, flags, niter, &result)) return r;
+    if (int r = run_fused(one, std::vector<int>{0}, flags, niter, &result, pl)) return r;
     return result;
   }
   int r = run_job(job, flags, niter, progprec, progress, userdata, /*eager=*/progress == nullptr);
-  if (r == JOB_RERUN_CAREFUL)
-    r = run_job(job, flags, niter, progprec, progress, userdata, /*eager=*/false);
+  if (r == JOB_RERUN_CAREFUL) r = careful();
   return r;
 }
 

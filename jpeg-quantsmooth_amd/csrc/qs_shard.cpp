@@ -288,7 +288,7 @@ static int land_all_if_no_copy(Bands& bands, bool upsample) {
 
 // ---------------------------------------------------------------------------
 // independent components: one plane set per band
-static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vector<int>& devices) {
+static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vector<int>& devices, ProgressPlan* plan) {
   const double t_start = wall_ms();
   Bands bands(devices.size());
   if (int r = open_bands(bands, devices)) return r;
@@ -316,6 +316,10 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
 
   const int diag = (flags & QS_DIAGONALS) != 0;
   if (trace_on()) for (Band& B : bands.b) { HIP_TRY(hipSetDevice(B.dev)); HIP_TRY(hipEventRecord(B.evT0, B.s)); }
+  // progress callback installed: one event per band and iteration, in enqueue order (iteration-major)
+  struct ItEv { int dev; hipEvent_t e; };
+  std::vector<ItEv> it_ev;
+  struct ItEvFree { std::vector<ItEv>& v; ~ItEvFree() { for (ItEv& x : v) { (void)hipSetDevice(x.dev); (void)hipEventDestroy(x.e); } } } it_ev_free{it_ev};
   // Pass A runs once; every pass B but the last writes the next iteration's pixel planes itself (fused pass A) into
   // the band's second set of planes -- plane (it & 1) is read, plane ((it + 1) & 1) written.
   for (int it = 0; it < niter; ++it) {
@@ -346,6 +350,12 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
       // the planes about to be written are the ones the neighbours pulled their halo rows from one iteration ago
       if (it < niter - 1) if (int r = before_overwrite(bands, d)) return r;
       qs_launch_smooth_set(B.set, diag, it == niter - 1, B.s);
+      if (plan) {                                              // progress: "iteration `it` is done on this band"
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        it_ev.push_back({B.dev, e});
+        HIP_TRY(hipEventRecord(e, B.s));
+      }
     }
   }
   if (trace_on()) for (Band& B : bands.b) { HIP_TRY(hipSetDevice(B.dev)); HIP_TRY(hipEventRecord(B.evT1, B.s)); }
@@ -361,6 +371,28 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
   }
   const double t_enq = wall_ms();
 
+  if (plan) {
+    // Progress (reference :2656-2664): the bands advance in lock step, so "iteration it of every component" is what
+    // completes; the calls whose share of the work that covers are made, in the reference's sequence, when the LAST
+    // band has finished the iteration.  A cancel ends like a tripped range check: the host input is untouched, the
+    // caller re-runs the job in the reference's order with the recorded answers (ProgressPlan::replay).
+    long long per_iter = 0;
+    for (int ci = 0; ci < job->ncomp; ++ci) per_iter += (long long)job->hblk[ci] * job->vsamp[ci];
+    const size_t nb = bands.b.size();
+    for (int it = 0; it < niter && !plan->cancelled; ++it) {
+      for (size_t d = 0; d < nb; ++d) {
+        const ItEv& x = it_ev[(size_t)it * nb + d];
+        HIP_TRY(hipSetDevice(x.dev));
+        HIP_TRY(hipEventSynchronize(x.e));
+      }
+      plan->advance(per_iter * (it + 1));
+    }
+    if (plan->cancelled) {
+      for (Band& B : bands.b) { HIP_TRY(hipSetDevice(B.dev)); HIP_TRY(hipStreamSynchronize(B.s)); }
+      if (trace_on()) fprintf(stderr, "qs_hip trace: sharded(set) cancelled by the progress callback\n");
+      return JOB_RERUN_CAREFUL;
+    }
+  }
   bool bad = false;
   if (int r = read_flags(bands, bad)) return r;
   if (bad) return JOB_RERUN_CAREFUL;                          // host input is still untouched
@@ -385,8 +417,8 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
       }
     }
     fprintf(stderr, "qs_hip trace: sharded(set) %d band(s)  upload+stage %.2f ms  enqueue %.2f ms  drain+scatter %.2f ms  "
-                    "iterations on device: max %.2f ms (per band:%s)\n",
-            n, t_up - t_start, t_enq - t_up, wall_ms() - t_enq, worst, per.c_str());
+                    "iterations on device: max %.2f ms (per band:%s)%s\n",
+            n, t_up - t_start, t_enq - t_up, wall_ms() - t_enq, worst, per.c_str(), plan ? "  progress: callback served from this route" : "");
   }
   for (int ci = 0; ci < job->ncomp; ++ci)                    // reference :2851-2859
     if (job->has_quant[ci]) for (int i = 0; i < 64; ++i) job->quant[ci][i] = 1;
@@ -704,12 +736,12 @@ std::vector<int> qsj::shard_devices_for(const qs_hip_job* job, int flags, int ni
   return devs;
 }
 
-int qsj::run_sharded(qs_hip_job* job, int flags, int niter, const std::vector<int>& devices) {
+int qsj::run_sharded(qs_hip_job* job, int flags, int niter, const std::vector<int>& devices, ProgressPlan* plan) {
   if (devices.empty()) return qs_fail(QS_HIP_EINVAL, "sharded job: empty device list");
   if (devices.size() > 64) return qs_fail(QS_HIP_EINVAL, "sharded job: more than 64 bands");
   // the caller's current device is put back on every path
   struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{current_device()};
-  if (job_fusable(job, flags)) return run_sharded_set(job, flags, niter, devices);
+  if (job_fusable(job, flags)) return run_sharded_set(job, flags, niter, devices, plan);
   if (colour_shardable(job, flags, niter)) return run_sharded_colour(job, flags, niter, devices);
   return qs_fail(QS_HIP_ENOTSUP, "sharded job: this flag / table combination runs on one device");
 }

@@ -1,11 +1,16 @@
 """GPU parity tests: the HIP path (through the flat C ABI) must be BIT-EXACT
 against the oracle / golden vectors for integer JCOEF output."""
+import os
+import sys
+from pathlib import Path
+
 import numpy as np
 import pytest
 
 from helpers import GPU_FLAG_MASK_UNSUPPORTED, assert_same_result, golden_names, inject_extreme_blocks, load_golden
 
 pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def _supported(flags):
@@ -177,6 +182,69 @@ def test_gpu_progress_and_cancel(gpu, oracle, synth):
             logs.append((calls, res))
         assert logs[0][0] == logs[1][0]
         assert_same_result(logs[0][1], logs[1][1], f"cancel_at={cancel_at}")
+
+
+_PROGRESS_CODE = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import jpegqs_pkg
+from helpers import assert_same_result
+from oracle.oracle import Oracle
+pkg = jpegqs_pkg.load(); gpu = pkg.HipQS(); oracle = Oracle()
+mode = sys.argv[1]
+if mode == "colour":                      # three independent components (4:2:0, --quality 3 flags): one plane set
+    j = pkg.synth.synth_ycc(208, 144, 2, 2, quality=40, seed=3)
+    coefs, quants = j["coefs"], j["quants"]
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(208, 144))
+else:
+    c, q = pkg.synth.synth_gray(264, 328, 50, seed=4)
+    coefs, quants, kw = [c], [q], {}
+niter = 4
+for progprec in (0, -1, 7):
+    # how many calls does the reference make?  (then: no cancel, and a cancel at every one of them)
+    n_calls = []
+    def count(_u, cur, mx): n_calls.append((cur, mx)); return 0
+    want_full = oracle.do_quantsmooth(coefs, quants, 1, niter, progprec=progprec, progress=count, **kw)
+    assert len(n_calls) >= 2
+    cancels = [None] + (list(range(len(n_calls))) if progprec == 0 else [0, len(n_calls) - 1])
+    for cancel_at in cancels:
+        logs = []
+        for impl in (gpu, oracle):
+            calls = []
+            def cb(_u, cur, mx, calls=calls):
+                calls.append((cur, mx))
+                return 1 if cancel_at is not None and len(calls) - 1 == cancel_at else 0
+            res = impl.do_quantsmooth(coefs, quants, 1, niter, progprec=progprec, progress=cb, **kw)
+            logs.append((calls, res))
+        assert logs[0][0] == logs[1][0], (mode, progprec, cancel_at, logs[0][0], logs[1][0])
+        assert_same_result(logs[0][1], logs[1][1], "%%s progprec=%%d cancel_at=%%s" %% (mode, progprec, cancel_at))
+print("PROGRESS_OK")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,env,route", [
+    ("gray", {}, "fused"),
+    ("colour", {}, "fused"),
+    ("gray", {"QS_HIP_SPLIT_BLOCKS": "60", "QS_HIP_BAND_BLOCKS": "40"}, "fused"),              # the plane cut into pipelined bands
+    ("gray", {"QS_HIP_DEVICES": "0,0,0", "QS_HIP_SHARD_MIN_BLOCKS": "1"}, "sharded(set)"),      # three logical devices
+    ("colour", {"QS_HIP_DEVICES": "0,0", "QS_HIP_SHARD_MIN_BLOCKS": "1"}, "sharded(set)"),
+], ids=["plane set", "plane set, three components", "pipelined bands", "three logical devices", "two logical devices, three components"])
+def test_gpu_progress_callback_on_the_fast_routes(mode, env, route):
+    """A progress callback (reference quantsmooth.h:2474-2482, 2656-2664; example.c:137-149 installs one) no longer
+    sends the job to the host-synchronised single-device route: the plane-set route, its pipelined bands and the
+    multi-device route make the reference's calls -- same arguments, same order -- as the work completes, and a cancel
+    at ANY call gives the reference's result (every call index at the default precision, first and last at two others).
+    QS_HIP_TRACE proves which route served the callback."""
+    import subprocess
+    e = dict(os.environ, QS_HIP_TRACE="1", **env)
+    r = subprocess.run([sys.executable, "-c", _PROGRESS_CODE % (str(ROOT), str(ROOT / "tests")), mode],
+                       capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=e)
+    assert r.returncode == 0 and "PROGRESS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    served = [l for l in r.stderr.splitlines() if l.startswith(f"qs_hip trace: {route}") and "progress: callback served from this route" in l]
+    cancelled = [l for l in r.stderr.splitlines() if "cancelled by the" in l and "callback" in l]
+    assert served, r.stderr[-3000:]
+    assert cancelled, r.stderr[-3000:]
 
 
 def test_gpu_plane_layer_device_resident(gpu, oracle, synth):
