@@ -30,7 +30,7 @@
 #include <stdlib.h>
 #include "../qs_device.h"
 
-#define QS_LDS_PITCH 65 /* dwords per coefficient-pair row, 64 lanes + 1 pad */
+/* QS_LDS_PITCH: qs_device.h */
 
 // --------------------------------------------------------------------------
 // small helpers

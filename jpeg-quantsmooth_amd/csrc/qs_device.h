@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #define QS_APRON_X 16
+#define QS_LDS_PITCH 65 /* recovery kernels: dwords per coefficient-pair row of a wave's LDS slice, 64 lanes + 1 pad */
 #define QS_TAB_MAX 272 /* floats per coefficient with DIAGONALS, 160 without */
 
 // algorithm flags, numerically identical to reference libjpegqs.h:16-23
@@ -41,8 +42,21 @@ struct QsConsts {
   // Everything the recovery loop needs about zigzag position k in ONE 16-byte record, fetched
   // with a single s_load_dwordx4 one coefficient ahead of its use:
   //   [0] nat[k] | nat[max(k-1,1)] << 8 | x2[k] << 16    [1] q[k] (low 16, unsigned) | x1[k] << 16
-  //   [2] range[k] (float bits)                            [3] 0
+  //   [2] range[k] (float bits)                            [3] what is a function of k alone, see QS_REC_* below
   int32_t rec[64][4];
+};
+// QsConsts::rec[k][3] (round 5): the per-coefficient scalars of the recovery loop that depend on k only, precomputed --
+// i = nat[k], u = i & 7, v = i >> 3, i_nxt = nat[max(k - 1, 1)]
+enum {
+  QS_REC_H_ANY = 1,        // u != 0: the horizontal section runs
+  QS_REC_H_SKIP4 = 2,      // u == 4: its terms with x = 1, 3, 5 have zero weight
+  QS_REC_H_EVEN = 4,       // u even: x = 3 has
+  QS_REC_V_ANY = 8,        // v != 0: the vertical section runs
+  QS_REC_V_SKIP4 = 16,     // v == 4
+  QS_REC_V_EVEN = 32,      // v even
+  QS_REC_LDS_SHIFT = 6,    // bits 6..19: byte offset of coefficient i in a lane's LDS column, (i >> 1) * 65 * 4 + (i & 1) * 2
+  QS_REC_NXT_SHIFT = 12    // bit 20 (value 0x100 after the shift): the NEXT coefficient has no horizontal section, its
+                           // first weight chunk is the border chunk, 256 bytes into its row
 };
 
 static inline int qs_plane_pitch(int wblk) {

@@ -29,7 +29,7 @@
 #include <stdlib.h>
 #include "qs_device.h"
 
-#define QS_LDS_PITCH 65 /* dwords per coefficient-pair row, 64 lanes + 1 pad */
+/* QS_LDS_PITCH (65 dwords per coefficient-pair row: 64 lanes + 1 pad) comes from qs_device.h: the host packs LDS offsets into QsConsts::rec */
 
 // --------------------------------------------------------------------------
 // small helpers

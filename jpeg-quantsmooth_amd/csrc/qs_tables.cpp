@@ -187,7 +187,19 @@ extern "C" int qs_hip_consts_build(void* host_out, const uint16_t quant[64], int
     c->rec[k][0] = c->nat[k] | (c->nat[kn] << 8) | (c->x2[k] << 16);
     c->rec[k][1] = (int32_t)(((uint32_t)c->q[k] & 0xffffu) | ((uint32_t)c->x1[k] << 16));
     memcpy(&c->rec[k][2], &c->range[k], sizeof(float));
-    c->rec[k][3] = 0;
+    {   // the scalars of the recovery loop that depend on k alone (qs_device.h: QS_REC_*)
+      const int i = c->nat[k], u = i & 7, v = i >> 3, i_nxt = c->nat[kn];
+      int m = 0;
+      if (u) m |= QS_REC_H_ANY;
+      if (u == 4) m |= QS_REC_H_SKIP4;
+      if (!(u & 1)) m |= QS_REC_H_EVEN;
+      if (v) m |= QS_REC_V_ANY;
+      if (v == 4) m |= QS_REC_V_SKIP4;
+      if (!(v & 1)) m |= QS_REC_V_EVEN;
+      m |= ((i >> 1) * QS_LDS_PITCH * 4 + (i & 1) * 2) << QS_REC_LDS_SHIFT;
+      if (!(i_nxt & 7)) m |= 0x100 << QS_REC_NXT_SHIFT;
+      c->rec[k][3] = m;
+    }
   }
   memcpy(c->tab, W.tab[diag], sizeof(c->tab));
   return QS_HIP_OK;
