@@ -49,7 +49,7 @@ struct Band {            // one (logical) device
   int dev = 0, index = 0;
   Streams* st = nullptr;                 // leased under `dev`
   hipStream_t s = nullptr;
-  hipEvent_t evA = nullptr, evX = nullptr;
+  hipEvent_t evA = nullptr, evX[2] = {nullptr, nullptr};   // evX: "my pulls of exchange n are done", alternating (see before_overwrite)
   hipEvent_t evT0 = nullptr, evT1 = nullptr;   // QS_HIP_TRACE only: first pass A .. last pass B on this band's stream
   std::vector<BandPlane> planes;
   DevBuf coef, px, cst, status, aux[8];   // aux: route-specific planes (colour route)
@@ -57,7 +57,7 @@ struct Band {            // one (logical) device
   Download down, down_up[2];
   std::vector<QsConsts> hc;
   QsPlaneSet set;
-  bool x_recorded = false;
+  int x_count = 0;                                           // exchanges this band has recorded an evX for
 };
 
 // All per-device resources of a sharded job.  Destruction order matters: first drain every
@@ -75,7 +75,7 @@ struct Bands {
     for (Band& B : b) {
       (void)hipSetDevice(B.dev);
       if (B.evA) (void)hipEventDestroy(B.evA);
-      if (B.evX) (void)hipEventDestroy(B.evX);
+      for (hipEvent_t e : B.evX) if (e) (void)hipEventDestroy(e);
       if (B.evT0) (void)hipEventDestroy(B.evT0);
       if (B.evT1) (void)hipEventDestroy(B.evT1);
       B.down.reset(); B.down_up[0].reset(); B.down_up[1].reset();
@@ -102,7 +102,7 @@ static int open_bands(Bands& bands, const std::vector<int>& devices) {
     B.st = lease.p; lease.p = nullptr;                       // Bands::~Bands gives it back
     B.s = B.st->s[0];
     HIP_TRY(hipEventCreateWithFlags(&B.evA, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&B.evX, hipEventDisableTiming));
+    for (hipEvent_t& e : B.evX) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (trace_on()) { HIP_TRY(hipEventCreate(&B.evT0)); HIP_TRY(hipEventCreate(&B.evT1)); }
   }
   // direct xGMI access between neighbouring devices (without it the runtime stages peer copies
@@ -163,17 +163,24 @@ static int exchange(Bands& bands, int nplanes, PlaneFn plane) {
   }
   for (Band& B : bands.b) {                                  // "my pulls are done" -- see before_overwrite
     HIP_TRY(hipSetDevice(B.dev));
-    HIP_TRY(hipEventRecord(B.evX, B.s));
-    B.x_recorded = true;
+    HIP_TRY(hipEventRecord(B.evX[B.x_count & 1], B.s));
+    ++B.x_count;
   }
   return QS_HIP_OK;
 }
 
-// before band d overwrites planes its neighbours may still be pulling from
-static int before_overwrite(Bands& bands, size_t d) {
+// Before band d overwrites planes its neighbours may still be pulling from: wait for the neighbours' "pulls done".
+// lag = 0: of the latest exchange.  lag = 1: of the exchange BEFORE the latest -- for a fused pass B, which reads the
+// planes the latest exchange filled and overwrites the OTHER set (ping-pong), last pulled from one exchange earlier:
+// the long kernel then does not queue behind the neighbours' current halo pulls.  Two alternating
+// events per band: a wait captures the record it was queued behind, the event is free again two exchanges later.
+static int before_overwrite(Bands& bands, size_t d, int lag = 0) {
   Band& B = bands.b[d];
-  if (d > 0 && bands.b[d - 1].x_recorded) HIP_TRY(hipStreamWaitEvent(B.s, bands.b[d - 1].evX, 0));
-  if (d + 1 < bands.b.size() && bands.b[d + 1].x_recorded) HIP_TRY(hipStreamWaitEvent(B.s, bands.b[d + 1].evX, 0));
+  for (size_t n : {d - 1, d + 1}) {
+    if (n >= bands.b.size()) continue;                       // (d - 1 wraps for d = 0)
+    const Band& N = bands.b[n];
+    if (N.x_count > lag) HIP_TRY(hipStreamWaitEvent(B.s, N.evX[(N.x_count - 1 - lag) & 1], 0));
+  }
   return QS_HIP_OK;
 }
 
@@ -348,7 +355,7 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
         B.set.ref[i].plane_next = it == niter - 1 ? nullptr : cur ? a : b;
       }
       // the planes about to be written are the ones the neighbours pulled their halo rows from one iteration ago
-      if (it < niter - 1) if (int r = before_overwrite(bands, d)) return r;
+      if (it < niter - 1) if (int r = before_overwrite(bands, d, /*lag=*/1)) return r;
       qs_launch_smooth_set(B.set, diag, it == niter - 1, B.s);
       if (plan) {                                              // progress: "iteration `it` is done on this band"
         hipEvent_t e = nullptr;
@@ -489,7 +496,7 @@ static int run_sharded_colour(qs_hip_job* job, int flags, int niter, const std::
       HIP_TRY(hipSetDevice(B.dev));
       const BandPlane& P = B.planes[ci];
       // (the plane about to be written is the one the neighbours pulled their halo rows from one pass earlier)
-      if (write_next) if (int r = before_overwrite(bands, d)) return r;
+      if (write_next) if (int r = before_overwrite(bands, d, /*lag=*/1)) return r;
       if (ci && joint) qs_launch_joint(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, lowres(B), P.wb, P.hb, 0, 0, B.s);
       qs_launch_smooth_plane(ref(B, ci).cst, ref(B, ci).coef, ref(B, ci).plane, write_next ? ref(B, ci).plane_next : nullptr,
                              !P.halo_top, !P.halo_bot, P.wb, P.hb, diag, comp_rebalance(job, ci, flags), final_clamp,

@@ -472,8 +472,12 @@ struct Download {
   // have_restore: the caller can put the pieces back should this fail half-way (it holds the pinned upload staging):
   // an UNSTAGED download (small, or pinned memory exhausted) then goes straight into the pieces, one blocking copy
   // each, instead of through a full-size temporary and a second host copy
+  // (only for a handful of pieces -- kDirectPieces: with the row-pointer entry point and rows that are not adjacent in
+  //  memory an image is thousands of pieces, i.e. thousands of small synchronous copies; those land in the temporary
+  //  and are scattered by the helper threads as before)
+  static constexpr size_t kDirectPieces = 16;
   hipError_t finish(const void* src, const std::vector<Piece>& pieces, hipStream_t s, bool have_restore = false) {
-    if (!staged && !landed && have_restore && bytes && !pieces.empty()) {
+    if (!staged && !landed && have_restore && bytes && !pieces.empty() && pieces.size() <= kDirectPieces) {
       hipError_t e = hipStreamSynchronize(s);
       for (size_t i = 0; i < pieces.size() && e == hipSuccess; ++i)
         e = hipMemcpy(pieces[i].host, static_cast<const char*>(src) + pieces[i].off, pieces[i].len, hipMemcpyDeviceToHost);

@@ -224,3 +224,42 @@ print("ok")
     nbands = (width // 8) * 128 // band_blocks
     env = {"QS_HIP_SPLIT_BLOCKS": "60", "QS_HIP_BAND_BLOCKS": str(band_blocks), "QS_HIP_TEST_HOOKS": "1"}
     assert "ok" in _run_py("import sys; sys.argv = ['x', '%d', '%d']\n" % (width, nbands) + code, env), kind
+
+
+@pytest.mark.parametrize("route", ["general", "fused", "sharded-set", "sharded-colour"])
+def test_direct_download_path_failure_leaves_the_image_untouched(gpu, oracle, synth, monkeypatch, route):
+    """an UNSTAGED download whose caller holds a restore copy goes straight into the caller's arrays
+    (Download::finish, direct path: a few blocking copies instead of a full-size temporary) and can fail half-way.
+    That combination arises when the pinned block of the DOWNLOAD cannot be had while the upload was staged.  Drive it
+    on every route: the k-th pinned request fails (k = 1..10 walks through upload staging, status words and download
+    staging of every component / band) and the 1st or 2nd landing reports a failure after writing.  Whatever happens,
+    either the call fails and the caller's arrays and tables are the input's, or it succeeds with the exact result."""
+    size = (2048, 1536)
+    big = synth.synth_ycc(size[0], size[1], 2, 2, quality=50, seed=13)
+    job = dict(coefs=big["coefs"], quants=big["quants"], hsamp=big["hsamp"], vsamp=big["vsamp"], colorspace=3, image_size=size)
+    flags, devices = {"general": (7, None), "fused": (1, None), "sharded-set": (1, [0, 0]), "sharded-colour": (7, [0, 0])}[route]
+    want = _want(oracle, job, flags, 2)
+    failed = ok = 0
+    for k in range(1, 11):
+        for nth in (1, 2):
+            monkeypatch.setenv("QS_HIP_TEST_FAIL_PINNED", str(k))
+            monkeypatch.setenv("QS_HIP_TEST_FAIL_FINISH", str(nth))
+            try:
+                rc, work, j = _raw_call(gpu, job, flags, 2, devices)
+            finally:
+                monkeypatch.delenv("QS_HIP_TEST_FAIL_PINNED")
+                monkeypatch.delenv("QS_HIP_TEST_FAIL_FINISH")
+            if rc < 0:
+                failed += 1
+                for ci in range(3):
+                    assert np.array_equal(work[ci], job["coefs"][ci]), f"{route} k={k} nth={nth}: component {ci} left modified after a reported failure"
+                    assert list(j.quant[ci][:]) == [int(v) for v in job["quants"][ci]], f"{route} k={k} nth={nth}: quant table {ci} changed"
+                assert j.up_wblk == 0
+            else:
+                ok += 1
+                got = gpu._job_result(j, work, job["quants"], rc)
+                assert_same_result(got, want, f"{route} k={k} nth={nth}: reported success")
+    assert failed > 0, "the injected landing failure never fired"
+    kw = {n: job[n] for n in ("hsamp", "vsamp", "colorspace", "image_size")}
+    again = gpu.do_quantsmooth(job["coefs"], job["quants"], flags, 2, devices=devices, **kw)
+    assert_same_result(again, want, f"{route}: the call after the injected failures")
