@@ -2,7 +2,7 @@
 # a FRESH 20,000-trial corpus (tools/fuzz_gpu.py gen build/fuzz_r04_20k.jsonl 20000 404, oracle only, on the build box) replayed in
 # four forms of pass B (all with the fused epilogue) and on the banded / sharded routes
 O=gpurun_out/${FUZZ_TAG:-r04_fuzz2}; mkdir -p $O
-F=build/fuzz_r04_20k.jsonl
+F=${FUZZ_FILE:-build/fuzz_r04_20k.jsonl}
 run() { name=$1; shift; ( time env "$@" python tools/fuzz_gpu.py run $F ) > $O/fuzz_$name.txt 2>&1; tail -4 $O/fuzz_$name.txt | head -2; }
 run default X=1
 run lane QS_HIP_DP=0
