@@ -125,6 +125,14 @@ int qs_hip_colour_band_rows(int hblk_luma, int hblk_chroma, int v_samp, int nban
 int qs_hip_band_halo_rows(int wblk, int hblk, size_t *send_top, size_t *send_bot,
 		size_t *recv_top, size_t *recv_bot, size_t *nbytes);
 
+/* The progress calls a job will make, as a function of its geometry (no device needed): the reference calls
+ * progress(userdata, cur, max) after a pass B whenever its running block-row count crosses a threshold
+ * (quantsmooth.h:2474-2482, 2656-2664); the pipelined routes of this library make exactly these calls, in this order,
+ * each when at least that share of the work has completed.  Fills cur_out[0 .. min(n, max_calls)) and *max_out (the
+ * `max` argument of every call) for a job whose components all run `niter` iterations (ordinary quant tables, no
+ * cross-component flags); returns the number of calls n. */
+int qs_hip_progress_calls(const qs_hip_job *geometry, int niter, int progprec, int *cur_out, int max_calls, int *max_out);
+
 /* Optional, returns at once: bring the GPU side up IN THE BACKGROUND while the caller is still busy with something
  * else -- typically libjpeg's entropy decoding between jpeg_read_header() and jpeg_read_coefficients().  A fresh
  * process otherwise pays for the HIP runtime, the device context, the code object and the pinned staging buffers

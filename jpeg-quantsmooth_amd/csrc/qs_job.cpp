@@ -412,6 +412,16 @@ int qsj::ProgressPlan::replay(void* self, int cur, int max) {
   return P->fn(P->userdata, cur, max);                      // beyond the record: live
 }
 
+extern "C" int qs_hip_progress_calls(const qs_hip_job* geometry, int niter, int progprec, int* cur_out, int max_calls, int* max_out) {
+  if (!geometry || geometry->ncomp < 1 || geometry->ncomp > QS_HIP_MAXC) return qs_fail(QS_HIP_EINVAL, "qs_hip_progress_calls: bad job");
+  niter = niter < 0 ? 0 : niter > 100 ? 100 : niter;       // reference :2455-2456
+  ProgressPlan plan;
+  plan.init(geometry, niter, progprec, nullptr, nullptr);
+  if (max_out) *max_out = plan.progprec_eff;
+  for (size_t k = 0; k < plan.calls.size() && cur_out && (int)k < max_calls; ++k) cur_out[k] = plan.calls[k].cur;
+  return (int)plan.calls.size();
+}
+
 bool qsj::job_fusable(const qs_hip_job* job, int flags) {
   static const bool off = getenv("QS_HIP_NO_FUSE") != nullptr;
   if (off || (flags & QS_LOW_QUALITY) || job_needs_lowres(job, flags)) return false;

@@ -94,6 +94,7 @@ ABI = {
     "qs_hip_colour_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4),
     "qs_hip_band_halo_rows": (C.c_int, [C.c_int, C.c_int] + [C.POINTER(C.c_size_t)] * 5),
     "qs_hip_prewarm": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int]),
+    "qs_hip_progress_calls": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "qs_hip_free": (None, [C.c_void_p]),
     "qs_hip_release_cache": (None, []),
     "qs_hip_device_count": (C.c_int, []),
@@ -281,6 +282,14 @@ class HipQS:
         cb = PROGRESS_FN(progress) if progress else C.cast(None, PROGRESS_FN)
         ret = self._check(self.lib.qs_hip_do_quantsmooth(C.byref(job), flags, niter, progprec, cb, None))
         return self._job_result(job, work, quants, ret)
+
+    def progress_calls(self, coefs, quants, niter, progprec=0, **kw):
+        """qs_hip_progress_calls: [(cur, max), ...] the progress callback of this job will see (no device needed)"""
+        job, _work = self._make_job(coefs, quants, kw.get("hsamp"), kw.get("vsamp"), kw.get("colorspace"), kw.get("image_size"))
+        out = (C.c_int * 4096)()
+        mx = C.c_int(0)
+        n = self._check(self.lib.qs_hip_progress_calls(C.byref(job), niter, progprec, out, 4096, C.byref(mx)))
+        return [(int(out[k]), int(mx.value)) for k in range(min(n, 4096))]
 
     def set_devices(self, devices):
         """qs_hip_set_devices: the device list large jobs are spread over ([] = default)"""

@@ -240,3 +240,29 @@ def test_prewarm_is_harmless_without_a_device(pkg, hip, synth):
         with pytest.raises(pkg.QsHipError) as ei:
             hip.do_quantsmooth([coef], [quant], 0, 1)
         assert ei.value.code == -1
+
+
+@pytest.mark.parametrize("progprec", [0, -1, 1, 7, 1000])
+def test_progress_plan_equals_the_reference_call_sequence(hip, oracle, reference, synth, progprec):
+    """CPU: the call sequence the pipelined GPU routes replay (ProgressPlan, exported as qs_hip_progress_calls: a
+    function of the geometry alone) against the calls the oracle port AND the compiled reference actually make
+    (quantsmooth.h:2474-2482, 2656-2664) -- gray, 4:2:0 and 4:4:4 with independent components, several niter"""
+    cases = []
+    c, q = synth.synth_gray(72, 40, 50, seed=2)
+    cases.append(([c], [q], {}))
+    for hs, vs in ((2, 2), (1, 1), (2, 1)):
+        j = synth.synth_ycc(104, 72, hs, vs, quality=50, seed=5)
+        cases.append((j["coefs"], j["quants"], dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(104, 72))))
+    for coefs, quants, kw in cases:
+        for niter in (1, 3, 4):
+            want = None
+            for impl in (oracle, reference):
+                calls = []
+
+                def cb(_u, cur, mx, calls=calls):
+                    calls.append((cur, mx))
+                    return 0
+                impl.do_quantsmooth(coefs, quants, 1, niter, progprec=progprec, progress=cb, **kw)
+                assert want is None or calls == want
+                want = calls
+            assert hip.progress_calls(coefs, quants, niter, progprec, **kw) == want, (len(coefs), niter, progprec)
