@@ -278,6 +278,38 @@ __device__ __forceinline__ void lds_set_coef(uint32_t* col, int i, int v) {
   *p = (lds_i16)v;
 }
 
+// The block's 64 coefficients out of the lane's LDS column, sign-extended, for the refresh IDCT: 64 ds_read_i16.
+// hipcc merges adjacent 16-bit LDS loads into dword reads and pays 48 VALU sign extensions per refresh for it (it
+// optimises for LDS instructions; this kernel is bound by VALU issue slots while the LDS pipe idles), so the reads are
+// issued by hand: four statements of sixteen loads, each with its own wait inside (form (i) of the guide's inline-asm
+// rules: loads and their s_waitcnt in ONE statement, early-clobber outputs -- nothing is in flight at a statement's end).
+// Row r of the column (coefficients 2r, 2r + 1) sits r * QS_LDS_PITCH dwords = r * 260 bytes in.
+static_assert(QS_LDS_PITCH * 4 == 260, "the literal offsets below assume a 260-byte row pitch");
+#define QS_LDS16_GROUP(BASE, W, N0) \
+  asm volatile("ds_read_i16 %0, %16\n\tds_read_i16 %1, %16 offset:2\n\t" \
+               "ds_read_i16 %2, %16 offset:260\n\tds_read_i16 %3, %16 offset:262\n\t" \
+               "ds_read_i16 %4, %16 offset:520\n\tds_read_i16 %5, %16 offset:522\n\t" \
+               "ds_read_i16 %6, %16 offset:780\n\tds_read_i16 %7, %16 offset:782\n\t" \
+               "ds_read_i16 %8, %16 offset:1040\n\tds_read_i16 %9, %16 offset:1042\n\t" \
+               "ds_read_i16 %10, %16 offset:1300\n\tds_read_i16 %11, %16 offset:1302\n\t" \
+               "ds_read_i16 %12, %16 offset:1560\n\tds_read_i16 %13, %16 offset:1562\n\t" \
+               "ds_read_i16 %14, %16 offset:1820\n\tds_read_i16 %15, %16 offset:1822\n\t" \
+               "s_waitcnt lgkmcnt(0)" \
+               : "=&v"(W[(N0) + 0]), "=&v"(W[(N0) + 1]), "=&v"(W[(N0) + 2]), "=&v"(W[(N0) + 3]), \
+                 "=&v"(W[(N0) + 4]), "=&v"(W[(N0) + 5]), "=&v"(W[(N0) + 6]), "=&v"(W[(N0) + 7]), \
+                 "=&v"(W[(N0) + 8]), "=&v"(W[(N0) + 9]), "=&v"(W[(N0) + 10]), "=&v"(W[(N0) + 11]), \
+                 "=&v"(W[(N0) + 12]), "=&v"(W[(N0) + 13]), "=&v"(W[(N0) + 14]), "=&v"(W[(N0) + 15]) \
+               : "v"(BASE) : "memory")
+__device__ __forceinline__ void lds_read_block_i16(const uint32_t* col, uint32_t (&ws)[64]) {
+  typedef const __attribute__((address_space(3))) uint32_t* lds_ptr;    // generic -> LDS address space: the DS byte address
+  const uint32_t a0 = (uint32_t)(uintptr_t)(lds_ptr)col;
+  const uint32_t a1 = a0 + 8 * 260, a2 = a0 + 16 * 260, a3 = a0 + 24 * 260;
+  QS_LDS16_GROUP(a0, ws, 0);
+  QS_LDS16_GROUP(a1, ws, 16);
+  QS_LDS16_GROUP(a2, ws, 32);
+  QS_LDS16_GROUP(a3, ws, 48);
+}
+
 // One term of the weighted least-squares sums, reference quantsmooth.h:1519-1520:
 //     t = max(R - |d|, 0); t *= t; x = d*t; y = w*t; num += x*y; den += y*y
 // evaluated in a power-of-two-scaled domain that needs one instruction less:
