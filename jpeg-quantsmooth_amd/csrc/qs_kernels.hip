@@ -409,6 +409,10 @@ typedef int qs_i4 __attribute__((ext_vector_type(4)));         // one per-coeffi
 // budget (168).  Measured A/B, identical results (profiles/r04d_hoist): 14, 20 and 26 hoisted differences are all
 // 2.3 % faster per plane launch at 8192^2 (1.597 -> 1.560 ms), 3 % at 128-512 block rows, +0.7 % in the 12-plane bench.
 #define QS_HOIST 20
+// Column-restricted pass 1 of the refresh (qs_smooth_kernel.inc): 1 = park the pass-1 outputs of two block columns in LDS
+#ifndef QS_STASH
+#define QS_STASH 1
+#endif
 
 // The recovery kernel (qs_smooth_kernel.inc): one plane, and a set of planes (job / batch layer: parameters come
 // from the plane set in the kernarg segment instead of from scalar arguments)
