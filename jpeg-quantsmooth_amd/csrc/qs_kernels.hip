@@ -409,6 +409,9 @@ typedef int qs_i4 __attribute__((ext_vector_type(4)));         // one per-coeffi
 // budget (168).  Measured A/B, identical results (profiles/r04d_hoist): 14, 20 and 26 hoisted differences are all
 // 2.3 % faster per plane launch at 8192^2 (1.597 -> 1.560 ms), 3 % at 128-512 block rows, +0.7 % in the 12-plane bench.
 #define QS_HOIST 20
+#ifndef QS_HOIST_DIAG
+#define QS_HOIST_DIAG 32   /* the DIAGONALS kernel: 152 VGPRs at 20 */
+#endif
 // Column-restricted pass 1 of the refresh (qs_smooth_kernel.inc): 1 = park the pass-1 outputs of two block columns in LDS
 #ifndef QS_STASH
 #define QS_STASH 1
