@@ -18,6 +18,7 @@ the N > 1 logic with the gloo backend.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 
@@ -517,6 +518,29 @@ class ColourBand:
                                  self.lowres_plane().data_ptr(), e.wblk, e.hblk, 0, 0, self._s())
         e.smooth_next(final_clamp, write_next, self.topo.rep_top, self.topo.rep_bot)
 
+    def pass_b_next_chroma(self, final_clamp, write_next):
+        """pass_b_next for Cb AND Cr at once: the two chroma planes are independent of each other (each depends on the final
+        luma only), so after their JOINT_YUV steps they go through the recovery kernel as ONE two-plane set launch
+        (qs_hip_smooth_planes_next) -- a 262 k-block chroma plane alone is 1.33 rounds of the chip's resident waves, two
+        together 2.67: less of the launch is spent in a partly filled last round.  Same arithmetic per block."""
+        hip, s = self.hip, self._s()
+        band = (0 if self.topo.rep_top else 1) | (0 if self.topo.rep_bot else 2)
+        planes = []
+        for ci in (1, 2):
+            e = self.eng[ci]
+            if self.joint:
+                hip.joint_plane(e.cst.data_ptr(), e.coef.data_ptr(), e.plane.data_ptr(),
+                                self.lowres_plane().data_ptr(), e.wblk, e.hblk, 0, 0, s)
+            if write_next:
+                e.ensure_plane2()
+            planes.append((e.cst.data_ptr(), e.coef.data_ptr(), e.plane.data_ptr(), e.status.data_ptr(), e.wblk, e.hblk, e.luma,
+                           band, e.plane2.data_ptr() if write_next else None))
+        hip.smooth_planes(hip.plane_refs(planes), self.eng[1].flags, final_clamp, s)
+        if write_next:
+            for ci in (1, 2):
+                e = self.eng[ci]
+                e.plane, e.plane2 = e.plane2, e.plane
+
     def clamp(self, ci):
         e = self.eng[ci]
         self.hip.clamp_plane(e.coef.data_ptr(), e.wblk, e.hblk, self._s())
@@ -612,17 +636,25 @@ def _run_colour_bands_fused(bands, exchange) -> None:
         for b in bands:
             b.downsample()
         exchange([b.planes_for_halo("L") for b in bands])
-    # ---- chroma
+    # ---- chroma: Cb and Cr advance together (independent of each other; one two-plane launch per iteration and band)
+    extra = bool(b0.upsample)
+    # (HipBandEngine; other engines: plane by plane.  QS_BANDS_CHROMA_PAIR=0: plane by plane, for A/B runs)
+    pair = hasattr(b0.eng[1], "plane2") and hasattr(b0.hip, "smooth_planes") and os.environ.get("QS_BANDS_CHROMA_PAIR", "1") != "0"
     for ci in (1, 2):
-        extra = bool(b0.upsample)
         for b in bands:
             b.pass_a(ci, True)
-        for it in range(niter):
+    for it in range(niter):
+        for ci in (1, 2):
             exchange([b.planes_for_halo(ci) for b in bands])
-            for b in bands:
-                b.pass_b_next(ci, it == niter - 1, it < niter - 1 or extra)
-        if extra:
-            exchange([b.planes_for_halo(ci) for b in bands])    # the refreshed plane's halo: the upsampling's 3x3 windows
+        for b in bands:
+            if pair:
+                b.pass_b_next_chroma(it == niter - 1, it < niter - 1 or extra)
+            else:
+                for ci in (1, 2):
+                    b.pass_b_next(ci, it == niter - 1, it < niter - 1 or extra)
+    if extra:
+        for ci in (1, 2):
+            exchange([b.planes_for_halo(ci) for b in bands])    # the refreshed planes' halo: the upsampling's 3x3 windows
             for b in bands:
                 b.upsample_chroma(ci, b.chroma_row0)
 
