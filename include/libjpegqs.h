@@ -14,12 +14,17 @@
  * the IrfanView plugin -- links against libjpegqs_hip_shim.so unchanged.
  * Include <jpeglib.h> (any libjpeg 6b..9, or libjpeg-turbo) before this file.
  *
- * Implementation: csrc/jpegqs_shim.c gathers the JBLOCKROWs of each component
- * into flat arrays and runs the whole coefficient-recovery path on the GPU
- * through include/jpegqs_hip.h.  There is no CPU fallback: without a usable
- * HIP device do_quantsmooth() reports the error on stderr, leaves the
- * coefficients and quantisation tables untouched (the file stays a valid
- * JPEG) and returns non-zero.
+ * Implementation: csrc/jpegqs_shim.c hands the JBLOCKROWs of each component to
+ * the GPU library (include/jpegqs_hip.h), which runs the whole
+ * coefficient-recovery path on the MI355X.  On a machine with NO visible HIP
+ * device the same job runs on the library's CPU back end (csrc/qs_cpu.c, same
+ * bit-exact results; announced on stderr) -- like the reference, the call then
+ * still delivers a smoothed image.  JPEGQS_BACKEND=hip in the environment
+ * forbids that route, JPEGQS_BACKEND=cpu forces it.  A GPU that is present but
+ * fails (out of memory, launch error) is not papered over: do_quantsmooth()
+ * reports the error on stderr, counts a libjpeg warning
+ * (srcinfo->err->num_warnings), leaves the coefficients and quantisation tables
+ * untouched (the file stays a valid JPEG) and returns non-zero.
  */
 #ifndef JPEGQS_H
 #define JPEGQS_H
@@ -29,7 +34,7 @@ extern "C" {
 #endif
 
 /* jpegqs_control_t.flags: algorithm bits 0-6, CPU cap bits 12-15 (accepted and
- * ignored here: there is no CPU path to cap), info/log bits 16-20. */
+ * ignored here: the reference's SIMD tiers do not exist), info/log bits 16-20. */
 enum {
 	JPEGQS_ITER_MAX        = 100,  /* niter is clamped to [0, 100] */
 	JPEGQS_DIAGONALS       = 1,    /* --quality >= 4: diagonal neighbour terms */
@@ -60,7 +65,7 @@ enum {
 typedef struct {
 	int flags;      /* JPEGQS_* bits */
 	int niter;      /* iterations, default 3 in the CLI */
-	int threads;    /* accepted for compatibility; the GPU path ignores it */
+	int threads;    /* CPU back end only (as in the reference); the GPU path ignores it */
 	int progprec;   /* progress granularity: 0 -> 20 steps, < 0 -> finest */
 	void *userdata; /* passed back to progress() */
 	int (*progress)(void *data, int cur, int max); /* non-zero return cancels */
@@ -74,10 +79,14 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 
 /* Not in the reference: why the calling thread's last do_quantsmooth() returned non-zero.
  * 0 = for the reference's own reasons (cancelled by progress(), rejected tables/coefficients: the
- * image is still decodable); < 0 = the GPU back end failed (no HIP device, out of memory, launch
- * error -- a QS_HIP_E* code of jpegqs_hip.h) and the image was left untouched. */
+ * image is still decodable); < 0 = the back end failed (out of memory, launch error, no HIP device
+ * while JPEGQS_BACKEND=hip -- a QS_HIP_E* code of jpegqs_hip.h) and the image was left untouched. */
 JPEGQS_ATTR
 int jpegqs_hip_backend_status(void);
+/* Not in the reference: which back end the calling thread's last do_quantsmooth() ran on --
+ * "hip", "cpu" (no HIP device was visible, or JPEGQS_BACKEND=cpu), "none" (nothing to do / failed). */
+JPEGQS_ATTR
+const char *jpegqs_hip_backend_name(void);
 
 /* Not in the reference: bring the GPU side up in the background while libjpeg is still decoding the file.
  * jpegqs_hip_prewarm(NULL, NULL) first thing in main() starts the HIP runtime; called again after

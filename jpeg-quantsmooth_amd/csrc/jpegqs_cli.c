@@ -1,11 +1,12 @@
 /*
  * jpegqs_cli.c -- `jpegqs` command-line transcoder on top of the drop-in
  * library (include/libjpegqs.h): JPEG in -> coefficient recovery on the GPU ->
- * JPEG out.  Same options, option syntax, defaults, marker handling and exit
- * codes as the reference CLI (reference quantsmooth.c:257-259, 288-393,
- * 471-489, 541-596, 626) so that scripts and the reference's GUI front-end can
- * call it unchanged; the implementation (table-driven parser, single code
- * path for file/stdio) is ours.
+ * JPEG out.  Same options, option syntax, defaults, marker handling, --verbose
+ * banner and exit codes as the reference CLI (reference quantsmooth.c:257-259,
+ * 288-393, 405-444, 471-489, 541-596, 626) so that scripts and the reference's
+ * GUI front-end can call it unchanged; the implementation (table-driven parser,
+ * single code path for file/stdio) is ours.  (The reference's own unmodified
+ * quantsmooth.c also builds against the library: oracle/Makefile `dropin`.)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,7 +21,7 @@ typedef struct { char shortname; const char *longname; int has_arg; int *dst; } 
 static void usage(const char *prog) {
 	fprintf(stderr,
 "JPEG Quant Smooth : " JPEGQS_COPYRIGHT " : " JPEGQS_VERSION "\n"
-"Back end: AMD MI355X (gfx950) through HIP -- no CPU fallback\n"
+"Back end: AMD MI355X (gfx950) through HIP; CPU back end when no HIP device is visible\n"
 "Uses libjpeg, run with \"--verbose 1\" to show its version and copyright\n"
 "\n"
 "Usage:\n"
@@ -29,7 +30,7 @@ static void usage(const char *prog) {
 "Options:\n"
 "  -q, --quality n   Quality setting (1-6, default is 3)\n"
 "  -n, --niter n     Number of iterations (default is 3)\n"
-"  -t, --threads n   Accepted for compatibility (the GPU path ignores it)\n"
+"  -t, --threads n   Set the number of CPU threads to use (CPU back end only)\n"
 "  -o, --optimize    Option for libjpeg to produce smaller output file\n"
 "  -v, --verbose n   Print libjpeg debug output\n"
 "  -i, --info n      Print quantsmooth debug output (default is 15)\n"
@@ -89,6 +90,34 @@ int main(int argc, char **argv) {
 		}
 		argi += consumed;
 	}
+	src.err = jpeg_std_error(&src_err);
+	if (verbose) {
+		/* reference quantsmooth.c:405-444: which libjpeg this is -- the compile-time number, then the version and
+		 * copyright strings of the library actually loaded, found in its message table (the version string sits
+		 * next to the copyright and starts with a digit); the level handed to libjpeg is one less */
+		const char *msg = NULL, *ver = NULL;
+		int n = src_err.last_jpeg_message;
+#ifdef LIBJPEG_TURBO_VERSION
+#define QS_STR2(x) #x
+#define QS_STR(x) QS_STR2(x)
+		fprintf(stderr, "Compiled with libjpeg-turbo version %s\n", QS_STR(LIBJPEG_TURBO_VERSION));
+#else
+		fprintf(stderr, "Compiled with libjpeg version %d\n", JPEG_LIB_VERSION);
+#endif
+		for (i = 0; i < n; i++) {
+			msg = src_err.jpeg_message_table[i];
+			if (msg && !memcmp(msg, "Copyright", 9)) break;
+		}
+		if (i < n) {
+			if (i + 1 < n) ver = src_err.jpeg_message_table[i + 1];
+			if (ver && (ver[0] < '0' || ver[0] > '9')) ver = NULL;
+			fprintf(stderr, "Version string: %s\n%s\n\n", ver ? ver : "not found", msg);
+		} else {
+			fprintf(stderr, "Copyright not found\n\n");
+		}
+		verbose--;
+		if (argc - argi == 0) return 1;              /* "jpegqs --verbose 1" alone: the banner was the point */
+	}
 	if (argc - argi != 2) { usage(prog); return 1; }
 
 	memset(&opts, 0, sizeof(opts));
@@ -109,7 +138,6 @@ int main(int argc, char **argv) {
 	 * (not for --niter 0 without upsampling: that is a plain transcode and needs no device) */
 	if (opts.niter > 0 || (opts.flags & JPEGQS_UPSAMPLE_UV)) jpegqs_hip_prewarm(NULL, NULL);
 
-	src.err = jpeg_std_error(&src_err);
 	jpeg_create_decompress(&src);
 	dst.err = jpeg_std_error(&dst_err);
 	jpeg_create_compress(&dst);
@@ -129,9 +157,11 @@ int main(int argc, char **argv) {
 	jpegqs_hip_prewarm(&src, &opts);      /* geometry known: the transfer buffers are set up during the decode */
 	coefs = jpeg_read_coefficients(&src);
 	/* The reference ignores the return value (its do_quantsmooth cannot fail, and a cancelled or
-	 * rejected run still leaves a decodable image, quantsmooth.c:550).  The GPU back end can fail:
-	 * then nothing was processed, and writing the input back out with exit code 0 would hand
-	 * scripts an unsmoothed file as a success. */
+	 * rejected run still leaves a decodable image, quantsmooth.c:550).  The GPU back end can fail
+	 * (a machine WITHOUT a GPU is not a failure: the library's CPU back end runs): then nothing was
+	 * processed, and writing the input back out would hand scripts an unsmoothed file.  (The
+	 * reference's own CLI on this library gets exit code 2 in that case: the library counts a
+	 * libjpeg warning.) */
 	if (do_quantsmooth(&src, coefs, &opts) && jpegqs_hip_backend_status() < 0) {
 		fprintf(stderr, "%s: GPU back end failed (code %d), no output written\n", prog, jpegqs_hip_backend_status());
 		jpeg_destroy_compress(&dst);

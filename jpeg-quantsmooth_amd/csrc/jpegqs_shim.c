@@ -9,7 +9,15 @@
  * (include/jpegqs_hip.h).  Behaviour mirrored from reference
  * quantsmooth.h:2404-2905; citations below.
  *
- * Build: cc -shared -fPIC jpegqs_shim.c -I<libjpeg include> -L.. -ljpegqs_hip
+ * Back ends (the reference's counterpart is its run-time dispatcher, libjpegqs.c:80-156, which always
+ * ends in a function that smooths the image): the GPU library whenever a HIP device is visible; the CPU
+ * back end of csrc/qs_cpu.c -- same job contract, same bit-exact results -- when NONE is (a box without a
+ * GPU still gets a smoothed file), announced on stderr.  JPEGQS_BACKEND=hip forbids the CPU route (the
+ * call then fails as before), JPEGQS_BACKEND=cpu (or QS_HIP_FORCE_CPU=1) forces it.  A GPU that is
+ * present but FAILS (out of memory, launch error) is never papered over with the CPU: the call reports
+ * the failure, counts a libjpeg warning and leaves the image untouched.
+ *
+ * Build: cc -shared -fPIC jpegqs_shim.c qs_cpu.c -fopenmp -I<libjpeg include> -L.. -ljpegqs_hip
  *        (no libjpeg symbols are needed unless TRANSCODE_ONLY is left undefined,
  *        in which case the four jinit_* entry points below come from libjpeg).
  */
@@ -22,6 +30,7 @@
 #include "jpeglib.h"
 #include "../../include/libjpegqs.h"
 #include "../../include/jpegqs_hip.h"
+#include "qs_cpu.h"
 
 #define logfmt(...) fprintf(stderr, __VA_ARGS__)
 
@@ -46,16 +55,36 @@ EXTERN(void) jinit_color_deconverter JPP((j_decompress_ptr));
 static __thread int qs_backend_status = 0;
 int jpegqs_hip_backend_status(void) { return qs_backend_status; }
 
+/* Which back end the calling thread's last do_quantsmooth() ran on: "hip", "cpu", or "none" (early-out /
+ * nothing ran).  Not in the reference. */
+static __thread const char *qs_backend_name = "none";
+const char *jpegqs_hip_backend_name(void) { return qs_backend_name; }
+
+/* 0 = GPU, 1 = CPU back end (csrc/qs_cpu.c).  The CPU is chosen only when NO HIP device is visible, or on
+ * request; *why receives the reason for the stderr notice. */
+static int use_cpu_backend(const char **why) {
+	const char *e = getenv("JPEGQS_BACKEND"), *f = getenv("QS_HIP_FORCE_CPU");
+	if (e && !strcmp(e, "hip")) return 0;
+	if (e && !strcmp(e, "cpu")) { *why = "JPEGQS_BACKEND=cpu"; return 1; }
+	if (f && *f && strcmp(f, "0")) { *why = "QS_HIP_FORCE_CPU is set"; return 1; }
+	if (qs_hip_device_count() <= 0) { *why = "no HIP device visible"; return 1; }
+	return 0;
+}
+
 /* The only memory this file holds across libjpeg calls that is not in libjpeg's own pool: the
  * two replacement chroma arrays the GPU library malloc'ed (UPSAMPLE_UV), between its return and
  * their copy into new virtual arrays.  Should a libjpeg error exit (longjmp) fall into that
  * window, the pointers stay parked here and the next call on this thread releases them. */
 static __thread void *qs_parked[2] = { NULL, NULL };
+static __thread int qs_parked_cpu = 0;          /* they came from the CPU back end (plain malloc) */
 /* ... and the component copies of the backing-store path (malloc'ed here) */
 static __thread int16_t *qs_copy[QS_HIP_MAXC] = { NULL, NULL, NULL, NULL };
 static void release_parked(void) {
 	int j;
-	for (j = 0; j < 2; j++) if (qs_parked[j]) { qs_hip_free(qs_parked[j]); qs_parked[j] = NULL; }
+	for (j = 0; j < 2; j++) if (qs_parked[j]) {
+		if (qs_parked_cpu) qs_cpu_free(qs_parked[j]); else qs_hip_free(qs_parked[j]);
+		qs_parked[j] = NULL;
+	}
 	for (j = 0; j < QS_HIP_MAXC; j++) if (qs_copy[j]) { free(qs_copy[j]); qs_copy[j] = NULL; }
 }
 
@@ -112,7 +141,8 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 	qs_hip_job job;
 	int16_t **rows[QS_HIP_MAXC] = { NULL, NULL, NULL, NULL };
 	int ci, i, ret, flags = opts->flags;
-	int upsampled = 0, in_place = 1;
+	int upsampled = 0, in_place = 1, on_cpu = 0, have_work;
+	const char *why_cpu = "";
 	double t0 = 0;
 	jpeg_component_info *comp;
 	JDIMENSION blk_y;
@@ -135,10 +165,23 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 				logfmt("\n");
 			}
 		}
-	if (flags & JPEGQS_INFO_CPU) logfmt("SIMD type: hip/gfx950 (%d device(s))\n", qs_hip_device_count());
+	/* the reference's early-out (quantsmooth.h:2458) needs no back end at all */
+	have_work = opts->niter > 0 || (flags & JPEGQS_UPSAMPLE_UV);
+	if (have_work) on_cpu = use_cpu_backend(&why_cpu);
+	if (flags & JPEGQS_INFO_CPU) {                  /* the reference's dispatcher prints its choice here (libjpegqs.c:141-145) */
+		if (on_cpu) logfmt("SIMD type: cpu back end (%s; %d blocks per vector, %s)\n", why_cpu, qs_cpu_lanes(), qs_cpu_isa());
+		else logfmt("SIMD type: hip/gfx950 (%d device(s))\n", qs_hip_device_count());
+	}
+	if (on_cpu) {
+		/* never silent: once per process, whatever the --info bits say */
+		static int announced = 0;
+		if (!__sync_lock_test_and_set(&announced, 1))
+			logfmt("jpegqs: %s -- using the CPU back end (%d blocks per vector, %s)\n", why_cpu, qs_cpu_lanes(), qs_cpu_isa());
+	}
 	if (flags & JPEGQS_INFO_TIME) t0 = now_ms();
 
 	qs_backend_status = 0;
+	qs_backend_name = "none";
 	release_parked();
 	if (srcinfo->num_components < 1 || srcinfo->num_components > QS_HIP_MAXC) {
 		logfmt("jpegqs-hip: unsupported component count %d\n", srcinfo->num_components);
@@ -219,15 +262,28 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 			logfmt("component[%i] : size %ix%i\n", ci, job.wblk[ci], job.hblk[ci]);
 		}
 
-	if (in_place)
-		ret = qs_hip_do_quantsmooth_rows(&job, (int16_t *const *const *)rows, flags & JPEGQS_FLAGS_MASK,
-				opts->niter, opts->progprec, opts->progress, opts->userdata);
-	else
-		ret = qs_hip_do_quantsmooth(&job, flags & JPEGQS_FLAGS_MASK, opts->niter, opts->progprec,
-				opts->progress, opts->userdata);
+	if (on_cpu) {
+		ret = qs_cpu_do_quantsmooth(&job, in_place ? (int16_t *const *const *)rows : NULL, flags & JPEGQS_FLAGS_MASK,
+				opts->niter, opts->threads, opts->progprec, opts->progress, opts->userdata);
+		if (ret < 0) logfmt("jpegqs: the CPU back end rejected the image (code %d)\n", ret);
+		else qs_backend_name = "cpu";
+	} else {
+		if (in_place)
+			ret = qs_hip_do_quantsmooth_rows(&job, (int16_t *const *const *)rows, flags & JPEGQS_FLAGS_MASK,
+					opts->niter, opts->progprec, opts->progress, opts->userdata);
+		else
+			ret = qs_hip_do_quantsmooth(&job, flags & JPEGQS_FLAGS_MASK, opts->niter, opts->progprec,
+					opts->progress, opts->userdata);
+		if (ret < 0) logfmt("jpegqs-hip: %s\n", qs_hip_last_error());
+		else if (have_work) qs_backend_name = "hip";
+	}
 	if (ret < 0) {
-		/* no CPU fallback by design: report and leave the image untouched */
-		logfmt("jpegqs-hip: %s\n", qs_hip_last_error());
+		/* A back end that FAILED left the image untouched; callers written against the reference only see
+		 * "non-zero" (cancelled / rejected: still a smoothed-so-far, decodable image) and its own CLI ignores even
+		 * that (reference quantsmooth.c:550).  So the failure is also counted as a libjpeg warning -- what every
+		 * libjpeg application checks after a damaged file, and what makes the reference's CLI end with its
+		 * documented exit code 2 (quantsmooth.c:626) instead of 0. */
+		srcinfo->err->num_warnings++;
 		qs_backend_status = ret;
 		release_parked();
 		return 1;
@@ -265,7 +321,7 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 		JDIMENSION uw = (JDIMENSION)job.up_wblk, uh = (JDIMENSION)job.up_hblk;
 		size_t rowbytes = (size_t)uw * sizeof(JBLOCK);
 		jvirt_barray_ptr up[2];
-		qs_parked[0] = job.coef_up[0]; qs_parked[1] = job.coef_up[1];
+		qs_parked[0] = job.coef_up[0]; qs_parked[1] = job.coef_up[1]; qs_parked_cpu = on_cpu;
 		for (ci = 0; ci < 2; ci++)
 			up[ci] = (*srcinfo->mem->request_virt_barray)
 					((j_common_ptr)srcinfo, JPOOL_IMAGE, FALSE, uw, uh, 1);
@@ -276,7 +332,8 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 						((j_common_ptr)srcinfo, up[ci], blk_y, 1, TRUE);
 				memcpy(buf[0], (char*)job.coef_up[ci] + rowbytes * blk_y, rowbytes);
 			}
-			qs_hip_free(job.coef_up[ci]); qs_parked[ci] = NULL;
+			if (on_cpu) qs_cpu_free(job.coef_up[ci]); else qs_hip_free(job.coef_up[ci]);
+			qs_parked[ci] = NULL;
 			coef_arrays[ci + 1] = up[ci];
 			srcinfo->comp_info[ci + 1].width_in_blocks = uw;
 			srcinfo->comp_info[ci + 1].height_in_blocks = uh;
@@ -341,11 +398,9 @@ boolean jpegqs_start_decompress(j_decompress_ptr cinfo, jpegqs_control_t *opts) 
 		}
 		do_quantsmooth(cinfo, jpeg_read_coefficients(cinfo), opts);
 		/* The reference ignores the return value here (cancelled / rejected: the image decodes as it
-		 * is).  A GPU back end can also FAIL; the image then decodes unsmoothed, and that must not
-		 * pass silently: it is counted as a libjpeg warning (cinfo->err->num_warnings, what
-		 * applications check after decoding a damaged file) and jpegqs_hip_backend_status() keeps
-		 * the code for callers that know about it. */
-		if (jpegqs_hip_backend_status() < 0) cinfo->err->num_warnings++;
+		 * is).  A back end can also FAIL; the image then decodes unsmoothed, and that does not pass
+		 * silently: do_quantsmooth() has counted it as a libjpeg warning (cinfo->err->num_warnings) and
+		 * jpegqs_hip_backend_status() keeps the code for callers that know about it. */
 		jpeg_start_output(cinfo, cinfo->input_scan_number);
 	}
 	return ret;

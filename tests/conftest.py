@@ -21,6 +21,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _gpu_tests_never_take_the_cpu_back_end(request, monkeypatch):
+    """libjpegqs.so runs its CPU back end when no HIP device is visible (csrc/qs_cpu.c).  A test marked `gpu` must
+    never pass that way: for those, JPEGQS_BACKEND=hip forbids the route (the call fails instead) -- also in the
+    CLIs and demo programs they start, which inherit the environment."""
+    if request.node.get_closest_marker("gpu") is not None:
+        monkeypatch.setenv("JPEGQS_BACKEND", "hip")
+        monkeypatch.delenv("QS_HIP_FORCE_CPU", raising=False)
+    yield
+
+
 @pytest.fixture(scope="session")
 def pkg():
     return jpegqs_pkg.load()

@@ -140,7 +140,9 @@ def test_early_outs_need_no_gpu(hip, synth):
 
 
 def test_no_silent_cpu_fallback(pkg, hip, synth):
-    """without a device the job layer must raise, not compute on the CPU"""
+    """the C ABI of the hot path (libjpegqs_hip.so) has no CPU route at all: without a device the job layer must
+    raise, not compute on the CPU.  (The reference-API library on top of it, libjpegqs.so, runs its own announced
+    CPU back end in that case: tests/test_cpu_backend.py::test_cpu_fallback_is_announced_and_can_be_forbidden.)"""
     if hip.device_count() > 0:
         pytest.skip("a GPU is present; covered by the gpu tests")
     coef, quant = synth.synth_gray(64, 64, 50)
@@ -186,19 +188,23 @@ def test_turbo_branch_of_the_shim_compiles_and_matches_reference_layout(turbo_nu
 
 
 def test_decode_mode_reports_a_backend_failure(hip):
-    """jpegqs_start_decompress() with no usable GPU: the reference API has no error return there (reference
-    quantsmooth.h:2880-2895 ignores do_quantsmooth's result), so the failure is counted as a libjpeg warning
-    and kept in jpegqs_hip_backend_status(); the demo program exits 3 instead of delivering unsmoothed pixels"""
+    """jpegqs_start_decompress() with no usable GPU and the CPU back end forbidden (JPEGQS_BACKEND=hip): the
+    reference API has no error return there (reference quantsmooth.h:2880-2895 ignores do_quantsmooth's result), so the
+    failure is counted as a libjpeg warning and kept in jpegqs_hip_backend_status(); the demo program exits 3 instead
+    of delivering unsmoothed pixels.  Without the variable the same call runs on the CPU back end and succeeds."""
     import os
     import subprocess
     demo = ROOT / "oracle" / "decode_hip"
     if not demo.exists():
         pytest.fail(f"{demo} not built (run __graft_entry__.build())")
-    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")     # hide every device
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1", JPEGQS_BACKEND="hip")     # hide every device
     r = subprocess.run([str(demo), "3", "2", str(ROOT / "tests" / "golden" / "cli" / "gray64.jpg")], capture_output=True, env=env)
     assert r.returncode == 3, (r.returncode, r.stderr.decode())
     assert b"no HIP device" in r.stderr and b"back end failed (status -1" in r.stderr
     assert r.stdout == b""
+    env.pop("JPEGQS_BACKEND")
+    r = subprocess.run([str(demo), "3", "2", str(ROOT / "tests" / "golden" / "cli" / "gray64.jpg")], capture_output=True, env=env)
+    assert r.returncode == 0 and b"using the CPU back end" in r.stderr and len(r.stdout) > 0
 
 
 def test_band_arithmetic_exported_from_c(hip):

@@ -41,14 +41,15 @@ def test_cli_usage_and_exit_code():
 
 
 def test_cli_without_gpu_fails_loudly_and_writes_nothing(hip, tmp_path):
-    """no CPU fallback: a back-end failure is an error exit (3) and no output file -- a script must
-    not receive an unsmoothed image with a success status"""
+    """JPEGQS_BACKEND=hip (the CPU back end forbidden; tests/test_cpu_backend.py covers the default): a back-end
+    failure is an error exit (3) and no output file -- a script must not receive an unsmoothed image with a success status"""
+    import os
     _need_cli()
     if hip.device_count() > 0:
         pytest.skip("GPU present")
     out = tmp_path / "o.jpg"
     r = subprocess.run([str(CLI), "-q", "3", "-i", "0", str(GOLD / "gray64.jpg"), str(out)],
-                       capture_output=True, text=True)
+                       capture_output=True, text=True, env=dict(os.environ, JPEGQS_BACKEND="hip"))
     assert "no HIP device" in r.stderr and "no output written" in r.stderr
     assert r.returncode == 3 and not out.exists()
     # --niter 0 takes the reference's early-out before any device is needed: plain transcode, exit 0
@@ -194,3 +195,129 @@ def test_cli_info_output_matches_reference(gpu, tmp_path):
             assert g.startswith("quantsmooth: ") and g.endswith("ms")
         else:
             assert g == w
+
+
+# ---- --verbose banner, exit code 2, and the reference's OWN front-ends on the library ---------------------------------------
+REFDIR = ROOT / "oracle" / "_ref"
+
+
+def _built(name):
+    p = REFDIR / name
+    if not p.exists():
+        pytest.skip(f"{p} did not travel with the tree (built by `make -C oracle ref dropin` where /root/reference is mounted)")
+    return p
+
+
+def _no_noise(text):
+    """stderr minus what is not the CLI's: the CPU back end's announcement (no-GPU boxes), a ROCm data-file notice"""
+    return [l for l in text.splitlines() if "using the CPU back end" not in l and "amdgpu.ids" not in l]
+
+
+def test_cli_verbose_banner_equals_the_reference_cli(tmp_path):
+    """reference quantsmooth.c:405-444: `--verbose n` (n > 0) prints which libjpeg this is, then hands n - 1 to libjpeg's
+    trace level; without file arguments it stops there with status 1 and NO usage text.  Line for line what the
+    reference's own CLI prints (both link the same libjpeg)."""
+    _need_cli()
+    ref_cli = _built("jpegqs_ref_none")
+    for args in (["-v", "1"], ["--verbose", "3"], ["-v2"]):
+        a = subprocess.run([str(CLI), *args], capture_output=True, text=True)
+        b = subprocess.run([str(ref_cli), *args], capture_output=True, text=True)
+        assert a.returncode == b.returncode == 1
+        assert a.stderr == b.stderr and "Compiled with libjpeg" in a.stderr and "Usage" not in a.stderr
+    # with files: banner + libjpeg's own trace output at level n - 1, identical too
+    for level in ("1", "2"):
+        oa, ob = tmp_path / "a.jpg", tmp_path / "b.jpg"
+        a = subprocess.run([str(CLI), "-v", level, "-q", "3", "-n", "0", "-i", "0", str(GOLD / "gray64.jpg"), str(oa)], capture_output=True, text=True)
+        b = subprocess.run([str(ref_cli), "-v", level, "-q", "3", "-n", "0", "-i", "0", str(GOLD / "gray64.jpg"), str(ob)], capture_output=True, text=True)
+        assert a.returncode == b.returncode == 0
+        assert _no_noise(a.stderr) == _no_noise(b.stderr)
+        assert oa.read_bytes() == ob.read_bytes()
+    # -v 0 is silent, and the usage text still comes for a wrong argument count
+    r = subprocess.run([str(CLI), "-v", "0"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage:" in r.stderr and "Compiled with" not in r.stderr
+
+
+def _truncated(tmp_path, src, frac=0.6):
+    data = (GOLD / f"{src}.jpg").read_bytes()
+    p = tmp_path / f"{src}.trunc.jpg"
+    p.write_bytes(data[: int(len(data) * frac)])
+    return p
+
+
+def _exit2_case(exe, ref_cli, tmp_path, env=None):
+    for src in ("gray64", "rgb141x93_420"):
+        t = _truncated(tmp_path, src)
+        for quality in ("3", "6"):
+            oa, ob = tmp_path / "a.jpg", tmp_path / "b.jpg"
+            a = subprocess.run([str(exe), "-q", quality, "-i", "0", str(t), str(oa)], capture_output=True, text=True, env=env)
+            b = subprocess.run([str(ref_cli), "-q", quality, "-i", "0", str(t), str(ob)], capture_output=True, text=True)
+            assert a.returncode == b.returncode == 2, (a.returncode, b.returncode, a.stderr)
+            assert "Premature end of JPEG file" in a.stderr
+            assert _no_noise(a.stderr) == _no_noise(b.stderr)
+            assert oa.read_bytes() == ob.read_bytes(), (src, quality)
+
+
+def test_cli_exit_code_2_on_libjpeg_warnings(tmp_path):
+    """reference quantsmooth.c:626: a file libjpeg warns about (here: cut off at 60 %) is still processed and written,
+    with exit status 2 -- same status, same stderr and same output bytes as the reference's CLI.  Runs on whatever back
+    end this box has (the GPU box: the GPU; the build container: the CPU back end)."""
+    _need_cli()
+    _exit2_case(CLI, _built("jpegqs_ref_none"), tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_cli_exit_code_2_on_libjpeg_warnings(gpu, tmp_path):
+    import os
+    _need_cli()
+    _exit2_case(CLI, _built("jpegqs_ref_none"), tmp_path, env=dict(os.environ, JPEGQS_BACKEND="hip"))
+    _exit2_case(_built("jpegqs_dropin"), _built("jpegqs_ref_none"), tmp_path, env=dict(os.environ, JPEGQS_BACKEND="hip"))
+
+
+CLI_GOLDEN_CASES = ([(src, ["-q", str(q), "-n", "3"], f"{src}.q{q}.ref.jpg")
+                     for src in ("gray64", "rgb141x93_420", "rgb141x93_444") for q in (2, 3, 4, 5, 6)]
+                    + [(src, ["-q", str(q), "-n", "3"], f"{src}.q{q}.ref.jpg")
+                       for src, q in (("cmyk96x64", 3), ("cmyk96x64", 4), ("cmyk96x64", 6), ("rgb120x88_prog", 3),
+                                      ("rgb120x88_prog", 6), ("rgb120x88_422_rst", 2), ("rgb120x88_422_rst", 5), ("rgb120x88_422_rst", 6))]
+                    + [("rgb141x93_420", args, f"rgb141x93_420.{tag}.ref.jpg")
+                       for tag, args in (("f33", ["-f", "33", "-n", "2"]), ("f20_n1", ["--flags", "20", "--niter", "1"]),
+                                         ("c0", ["-q", "3", "-n", "3", "-c", "0"]), ("c1", ["-q", "3", "-n", "3", "--copy", "1"]),
+                                         ("q5_n0", ["-q", "5", "-n", "0"]), ("q6_n1_o", ["-q", "6", "-n", "1", "-o"]))])
+
+
+@pytest.mark.gpu
+def test_gpu_reference_cli_on_the_library_writes_the_reference_bytes(gpu, tmp_path):
+    """THE drop-in claim, literally: the reference's own UNMODIFIED quantsmooth.c, compiled from where it lies and linked
+    against libjpegqs.so + libjpegqs_hip.so (oracle/Makefile `dropin`; JPEGQS_BACKEND=hip: the GPU or nothing), writes
+    byte for byte what the same source writes on top of the reference's own implementation -- every CLI golden, --quality
+    2..6, every option case"""
+    import os
+    exe = _built("jpegqs_dropin")
+    env = dict(os.environ, JPEGQS_BACKEND="hip")
+    out = tmp_path / "o.jpg"
+    for src, args, ref in CLI_GOLDEN_CASES:
+        r = subprocess.run([str(exe), *args, "-i", "16", str(GOLD / f"{src}.jpg"), str(out)], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, (src, args, r.stderr)
+        assert "SIMD type: hip/gfx950" in r.stderr and "CPU back end" not in r.stderr
+        assert out.read_bytes() == (GOLD / ref).read_bytes(), (src, args)
+        out.unlink()
+
+
+@pytest.mark.gpu
+def test_gpu_reference_example_program_on_the_library(gpu, tmp_path):
+    """the reference's unmodified example.c (decode mode through jpegqs_start_decompress, the q6 flag set, niter 3 and a
+    progress callback that prints percentages -- example.c:96, 137-149) on the library vs on the reference itself: same
+    BMP bytes, same stdout (the callback sequence), same exit status"""
+    import os
+    ours, theirs = _built("example_dropin"), _built("example_ref_none")
+    env = dict(os.environ, JPEGQS_BACKEND="hip")
+    for src in ("gray64", "rgb141x93_444", "rgb141x93_420", "rgb120x88_422_rst", "cmyk96x64", "rgb128x96_420"):
+        a, b = tmp_path / "a.bmp", tmp_path / "b.bmp"
+        ra = subprocess.run([str(ours), str(GOLD / f"{src}.jpg"), str(a)], capture_output=True, env=env)
+        rb = subprocess.run([str(theirs), str(GOLD / f"{src}.jpg"), str(b)], capture_output=True)
+        assert ra.returncode == rb.returncode, (src, ra.stderr)   # (libjpeg 9 cannot decode after UPSAMPLE_UV of 4:2:0: both 1)
+        assert ra.stdout == rb.stdout, src
+        assert b"CPU back end" not in ra.stderr
+        assert a.exists() == b.exists()
+        if a.exists():
+            assert a.read_bytes() == b.read_bytes(), src
+            a.unlink(); b.unlink()

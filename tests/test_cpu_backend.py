@@ -1,0 +1,240 @@
+"""The CPU back end of libjpegqs.so (csrc/qs_cpu.c): what do_quantsmooth() runs when NO
+HIP device is visible.  Checked DIRECTLY against the compiled, unmodified reference (oracle/_ref, scalar build) -- not
+against the oracle port -- on the golden jobs, on 200 random jobs and through both command-line front-ends: the
+repository's `jpegqs` and the reference's own unmodified quantsmooth.c / example.c linked against the library
+(oracle/Makefile target `dropin`).  None of these tests needs a GPU; they hide every device."""
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from helpers import assert_same_result, golden_names, inject_extreme_blocks, load_golden
+
+ROOT = Path(__file__).resolve().parent.parent
+PKG = ROOT / "jpeg-quantsmooth_amd"
+CSRC = PKG / "csrc"
+CLI = PKG / "jpegqs"
+GOLD = ROOT / "tests" / "golden" / "cli"
+REFDIR = ROOT / "oracle" / "_ref"
+NO_GPU = dict(HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("JPEGQS_BACKEND", "QS_HIP_FORCE_CPU")}
+    env.update(NO_GPU)
+    env.update(extra)
+    return env
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    from cpu_backend import CpuBackend
+    return CpuBackend()
+
+
+def _dropin(name):
+    p = REFDIR / name
+    if not p.exists():
+        if Path("/root/reference/quantsmooth.c").exists():
+            subprocess.run(["make", "-s", "-C", str(ROOT / "oracle"), "dropin"], check=True)
+        if not p.exists():
+            pytest.skip(f"{p} not built and /root/reference not mounted")
+    return p
+
+
+# ---- the job itself, against the reference -------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("by_rows", [False, True], ids=["flat arrays", "one pointer per block row"])
+@pytest.mark.parametrize("name", golden_names())
+def test_cpu_backend_matches_golden(cpu, name, by_rows):
+    """tests/golden/*.npz are outputs of the compiled reference (tests/golden/make_golden.py)"""
+    job, want = load_golden(name)
+    got = cpu.do_quantsmooth(job["coefs"], job["quants"], job["flags"], job["niter"], by_rows=by_rows, **job["kw"])
+    assert_same_result(got, want, name)
+
+
+LAYOUTS = [(1, 1), (2, 2), (2, 1), (1, 2), (4, 1), (2, 2)]
+
+
+def _fuzz_job(synth, rng, trial):
+    w, h = int(rng.integers(8, 200)), int(rng.integers(8, 150))
+    qual = int(rng.choice([1, 5, 20, 35, 50, 65, 80, 95, 100]))
+    if rng.random() < 0.3:
+        coef, quant = synth.synth_gray(w, h, qual, seed=trial)
+        if rng.random() < 0.3:
+            coef = (coef * (rng.random(coef.shape[:2]) < 0.3)[:, :, None]).astype(np.int16)
+        return dict(coefs=[coef], quants=[quant]), f"gray {w}x{h} q{qual}"
+    hs, vs = LAYOUTS[int(rng.integers(0, len(LAYOUTS)))]
+    y = synth.synth_ycc(w, h, hs, vs, quality=qual, seed=trial)
+    if rng.random() < 0.5 and qual >= 20:
+        y = inject_extreme_blocks(y, seed=trial)
+    return (dict(coefs=y["coefs"], quants=y["quants"], hsamp=y["hsamp"], vsamp=y["vsamp"], colorspace=3, image_size=(w, h)),
+            f"ycc {w}x{h} {hs}x{vs} q{qual}")
+
+
+def test_cpu_backend_fuzz_against_the_compiled_reference(cpu, reference, synth):
+    """200 random jobs -- every flag combination, gray / 4:4:4 / 4:2:0 / 4:2:2 / 4:4:0 / 4:1:1, odd sizes, sparse planes,
+    blocks beyond the +-1023 clamp -- bit for bit against oracle/_ref/libqsref_none.so"""
+    for trial in range(200):
+        rng = np.random.default_rng([606, trial])
+        flags = int(rng.integers(0, 128)) & 0x3f
+        niter = int(rng.choice([0, 1, 2, 3, 3]))
+        j, desc = _fuzz_job(synth, rng, trial)
+        kw = {k: v for k, v in j.items() if k not in ("coefs", "quants")}
+        want = reference.do_quantsmooth(j["coefs"], j["quants"], flags, niter, threads=4, **kw)
+        got = cpu.do_quantsmooth(j["coefs"], j["quants"], flags, niter, by_rows=bool(trial & 1), **kw)
+        assert_same_result(got, want, f"trial {trial}: {desc} flags {flags} niter {niter}")
+
+
+def test_cpu_backend_hostile_inputs(cpu, reference, synth):
+    """damaged tables and coefficients (reference quantsmooth.h:2497-2511, 2599-2610): zero multipliers, a multiplier
+    >= 0x800 (stop before anything runs; later components are dequantised only), an out-of-range product in a later
+    component, an all-ones table, a component without a table"""
+    y = synth.synth_ycc(120, 88, 2, 2, quality=50, seed=3)
+    kw = dict(hsamp=y["hsamp"], vsamp=y["vsamp"], colorspace=3, image_size=(120, 88))
+
+    def both(coefs, quants, flags, niter, what):
+        want = reference.do_quantsmooth(coefs, quants, flags, niter, **kw)
+        got = cpu.do_quantsmooth(coefs, quants, flags, niter, **kw)
+        assert_same_result(got, want, what)
+        return got
+
+    for flags in (0, 1, 7, 15):
+        q = [t.copy() for t in y["quants"]]; q[0][5] = 0; q[1][63] = 0
+        both(y["coefs"], q, flags, 2, "zero multipliers")
+        q = [t.copy() for t in y["quants"]]; q[1][10] = 0x800
+        assert both(y["coefs"], q, flags, 2, "multiplier 0x800 in Cb")["ret"] == 1
+        q = [t.copy() for t in y["quants"]]; q[0][0] = 0xffff
+        assert both(y["coefs"], q, flags, 2, "multiplier 0xffff in Y")["ret"] == 1
+        c = [t.copy() for t in y["coefs"]]; c[2][1, 2, 0] = 0x7ff
+        assert both(c, y["quants"], flags, 2, "coefficient out of range in Cr")["ret"] == 1
+        c = [t.copy() for t in y["coefs"]]; c[0][0, 0, 3] = -0x7000
+        assert both(c, y["quants"], flags, 3, "coefficient out of range in Y")["ret"] == 1
+        q = [t.copy() for t in y["quants"]]; q[0][:] = 1
+        both(y["coefs"], q, flags, 2, "all-ones luma table")
+        if not flags & 4:     # (with UPSAMPLE_UV the reference itself dereferences the missing replacement array)
+            both(y["coefs"], [y["quants"][0], None, y["quants"][2]], flags, 2, "Cb without a table")
+        both(y["coefs"], [None, y["quants"][1], y["quants"][2]], flags, 2, "Y without a table")
+
+
+@pytest.mark.parametrize("progprec", [0, 7, -1, 1000])
+def test_cpu_backend_progress_and_cancel(cpu, reference, synth, progprec):
+    """the callback sees the reference's (cur, max) sequence, and a non-zero return stops where the reference stops
+    (reference quantsmooth.h:2474-2482, 2656-2664)"""
+    y = synth.synth_ycc(141, 93, 2, 2, quality=50, seed=5)
+    kw = dict(hsamp=y["hsamp"], vsamp=y["vsamp"], colorspace=3, image_size=(141, 93))
+    for flags in (0, 7):
+        for cancel_at in (None, 1, 4):
+            seen = {"ref": [], "cpu": []}
+
+            def cb(tag):
+                def f(_u, cur, mx):
+                    seen[tag].append((cur, mx))
+                    return int(cancel_at is not None and len(seen[tag]) >= cancel_at)
+                return f
+            want = reference.do_quantsmooth(y["coefs"], y["quants"], flags, 3, progprec=progprec, progress=cb("ref"), **kw)
+            got = cpu.do_quantsmooth(y["coefs"], y["quants"], flags, 3, progprec=progprec, progress=cb("cpu"), **kw)
+            assert seen["cpu"] == seen["ref"] and len(seen["ref"]) > 0
+            assert_same_result(got, want, f"flags {flags} cancel at call {cancel_at}")
+
+
+def test_cpu_backend_is_independent_of_thread_count(cpu, synth):
+    coef, quant = synth.synth_gray(520, 264, 50)
+    base = cpu.do_quantsmooth([coef], [quant], 1, 3, threads=1)
+    for threads in (0, 3, -1):
+        got = cpu.do_quantsmooth([coef], [quant], 1, 3, threads=threads)
+        assert np.array_equal(got["coefs"][0], base["coefs"][0])
+
+
+def test_cpu_backend_every_lane_count_and_the_baseline_isa(cpu, synth, tmp_path):
+    """the lane kernels are cloned per ISA (avx512f / avx2 / baseline, picked by the loader); rebuilt here without
+    clones (baseline x86-64 code) and with 4 and 8 blocks per vector: same coefficients -- the result does not depend
+    on the vector width, only each lane's own scalar-order chain"""
+    import ctypes as C
+    from cpu_backend import CpuBackend
+    y = synth.synth_ycc(333, 141, 2, 2, quality=35, seed=9)
+    kw = dict(hsamp=y["hsamp"], vsamp=y["vsamp"], colorspace=3, image_size=(333, 141))
+    want = {flags: cpu.do_quantsmooth(y["coefs"], y["quants"], flags, 2, **kw) for flags in (0, 1, 7)}
+    for lanes in (4, 8):
+        so = tmp_path / f"qs_cpu_{lanes}.so"
+        subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fwrapv", "-fopenmp", "-DQS_CPU_NO_CLONES",
+                        f"-DQS_NL={lanes}", "-o", str(so), str(CSRC / "qs_cpu.c"), "-lm"], check=True)
+        alt = CpuBackend.__new__(CpuBackend)
+        alt.lib = C.CDLL(str(so))
+        CpuBackend._bind(alt)
+        assert alt.lanes() == lanes and alt.isa() == "generic"
+        for flags, w in want.items():
+            assert_same_result(alt.do_quantsmooth(y["coefs"], y["quants"], flags, 2, **kw), w, f"{lanes} lanes, flags {flags}")
+
+
+# ---- behind the libjpeg API: the two CLIs without a GPU ------------------------------------------------------------------
+
+CLI_CASES = ([(src, ["-q", str(q), "-n", "3"], f"{src}.q{q}.ref.jpg")
+              for src in ("gray64", "rgb141x93_420", "rgb141x93_444") for q in (2, 3, 4, 5, 6)]
+             + [(src, ["-q", str(q), "-n", "3"], f"{src}.q{q}.ref.jpg")
+                for src, q in (("cmyk96x64", 3), ("cmyk96x64", 4), ("cmyk96x64", 6), ("rgb120x88_prog", 3), ("rgb120x88_prog", 6),
+                               ("rgb120x88_422_rst", 2), ("rgb120x88_422_rst", 5), ("rgb120x88_422_rst", 6))]
+             + [("rgb141x93_420", args, f"rgb141x93_420.{tag}.ref.jpg")
+                for tag, args in (("f33", ["-f", "33", "-n", "2"]), ("f20_n1", ["--flags", "20", "--niter", "1"]),
+                                  ("c0", ["-q", "3", "-n", "3", "-c", "0"]), ("c1", ["-q", "3", "-n", "3", "--copy", "1"]),
+                                  ("q5_n0", ["-q", "5", "-n", "0"]), ("q6_n1_o", ["-q", "6", "-n", "1", "-o"]))])
+
+
+@pytest.mark.parametrize("front_end", ["jpegqs (this repository's CLI)", "the reference's unmodified quantsmooth.c on libjpegqs.so"])
+def test_cli_without_a_gpu_writes_the_reference_bytes(front_end, tmp_path):
+    """every CLI golden (bytes written by the reference's own CLI, scalar build): with all HIP devices hidden both
+    front-ends exit 0, say on stderr that the CPU back end ran, and write exactly those bytes"""
+    exe = CLI if front_end.startswith("jpegqs") else _dropin("jpegqs_dropin")
+    assert exe.exists(), f"{exe} not built (run __graft_entry__.build())"
+    out = tmp_path / "o.jpg"
+    for src, args, ref in CLI_CASES:
+        r = subprocess.run([str(exe), *args, "-i", "0", str(GOLD / f"{src}.jpg"), str(out)], capture_output=True, text=True, env=_env())
+        assert r.returncode == 0, (src, args, r.stderr)
+        if "-n" in args and args[args.index("-n") + 1] == "0" and "6" not in args:
+            assert "CPU back end" not in r.stderr          # the reference's early-out: no back end was needed
+        else:
+            assert "using the CPU back end" in r.stderr, (src, args, r.stderr)
+        assert out.read_bytes() == (GOLD / ref).read_bytes(), (src, args)
+        out.unlink()
+
+
+def test_cpu_fallback_is_announced_and_can_be_forbidden(tmp_path):
+    """never silent: one stderr line per process plus the --info 16 line; JPEGQS_BACKEND=hip forbids the route -- the
+    repository's CLI then exits 3 without an output file, the reference's own CLI (which ignores do_quantsmooth's return
+    value, quantsmooth.c:550) ends with its documented warning status 2 (quantsmooth.c:626) instead of 0"""
+    out = tmp_path / "o.jpg"
+    src = str(GOLD / "gray64.jpg")
+    r = subprocess.run([str(CLI), "-q", "3", "-i", "16", src, str(out)], capture_output=True, text=True, env=_env())
+    assert r.returncode == 0
+    assert "SIMD type: cpu back end (no HIP device visible" in r.stderr
+    assert r.stderr.count("using the CPU back end") == 1
+    out.unlink()
+    r = subprocess.run([str(CLI), "-q", "3", "-i", "0", src, str(out)], capture_output=True, text=True, env=_env(JPEGQS_BACKEND="hip"))
+    assert r.returncode == 3 and not out.exists()
+    assert "no HIP device" in r.stderr and "no output written" in r.stderr
+    r = subprocess.run([str(CLI), "-q", "3", "-i", "0", src, str(out)], capture_output=True, text=True, env=_env(JPEGQS_BACKEND="cpu"))
+    assert r.returncode == 0 and "JPEGQS_BACKEND=cpu" in r.stderr
+    assert out.read_bytes() == (GOLD / "gray64.q3.ref.jpg").read_bytes()
+    ref_cli = _dropin("jpegqs_dropin")
+    r = subprocess.run([str(ref_cli), "-q", "3", "-i", "0", src, str(out)], capture_output=True, text=True, env=_env(JPEGQS_BACKEND="hip"))
+    assert r.returncode == 2, (r.returncode, r.stderr)    # was 0 (silently unsmoothed) before the warning was counted
+    assert "no HIP device" in r.stderr
+
+
+def test_reference_example_program_on_the_library_without_a_gpu(tmp_path):
+    """the reference's unmodified example.c (decode mode, q6 flags, niter 3, a progress callback that prints
+    percentages, example.c:96, 137-149) linked against libjpegqs.so: same BMP bytes, same stdout and same exit code as
+    the same source on the reference itself"""
+    ours, theirs = _dropin("example_dropin"), _dropin("example_ref_none")
+    for src in ("gray64", "rgb141x93_444", "rgb141x93_420", "rgb120x88_422_rst", "cmyk96x64"):
+        a, b = tmp_path / "a.bmp", tmp_path / "b.bmp"
+        ra = subprocess.run([str(ours), str(GOLD / f"{src}.jpg"), str(a)], capture_output=True, env=_env())
+        rb = subprocess.run([str(theirs), str(GOLD / f"{src}.jpg"), str(b)], capture_output=True, env=_env())
+        assert ra.returncode == rb.returncode, src          # (libjpeg 9 cannot decode after UPSAMPLE_UV of 4:2:0: both exit 1)
+        assert ra.stdout == rb.stdout, src
+        assert a.exists() == b.exists()
+        if a.exists():
+            assert a.read_bytes() == b.read_bytes(), src
+            a.unlink(); b.unlink()
