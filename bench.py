@@ -473,28 +473,51 @@ def _batch_size(args, nsteps, bytes_per_plane):
     return max(1, min(want, RESIDENT_BUDGET // max(1, nsteps * bytes_per_plane)))
 
 
+def _device_delay(torch, stream):
+    """-> f(us): queue a device-side wait of about `us` microseconds on the stream (a spinning kernel, torch.cuda._sleep,
+    calibrated here with HIP events), or None when it cannot be had.  Stands in for the latency of a halo exchange: the
+    receiving stream is idle until the neighbour's row has arrived."""
+    sleep = getattr(torch.cuda, "_sleep", None)
+    if sleep is None:
+        return None
+    try:
+        sleep(1000); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 2_000_000
+        e0.record(stream); sleep(n); e1.record(stream); torch.cuda.synchronize()
+        per_us = n / (e0.elapsed_time(e1) * 1e3)
+        if not per_us > 0:
+            return None
+    except Exception:  # noqa: BLE001
+        return None
+    return lambda us: sleep(int(us * per_us)) if us > 0 else None
+
+
 def _scaling_emulation(torch, hip, bands, full, quant, flags, niter, dev, hblk_total, steps=8):
     """ms per single-image step of the middle 1/N band for N = 1, 2, 4, 8 (batch = 1: one plane, one launch per pass),
-    the mean pass-B launch time by HIP events, and the implied speed-up over N = 1"""
-    out = {"what": "one rank's share of a single-image N-GPU step on THIS GPU: middle 1/N band of one plane, "
-                   "niter x {pass A, 2 halo rows in + out as device copies, pass B}; no interconnect latency",
-           "ms_per_step": {}, "pass_b_us": {}, "speedup_vs_1": {}}
+    the mean pass-B launch time by HIP events, and the implied speed-up over N = 1 -- for the per-iteration halo
+    exchange with an injected exchange latency of 0 / 25 / 50 / 100 us, and for the communication-avoiding schedule
+    (niter extra block rows per cut side, no exchange: bands.deep_band_rows)"""
+    delays = (0, 25, 50, 100)
+    out = {"what": "one rank's share of a single-image N-GPU step on THIS GPU: middle 1/N band of one plane.  exchange schedule: "
+                   "pass A once, niter x {2 halo rows in + out as device copies, pass B}, each exchange followed by a device-side "
+                   "wait of 0 / 25 / 50 / 100 us (stand-in for the interconnect latency; speedup_vs_1 = no wait).  deep_halo: "
+                   "the communication-avoiding schedule, niter extra block rows per cut side, no exchange at all",
+           "ms_per_step": {}, "pass_b_us": {}, "speedup_vs_1": {}, "exchange_latency_us": {}, "deep_halo": {"ms_per_step": {}, "speedup_vs_1": {}, "rows": {}}}
     stream = torch.cuda.current_stream()
-    for n in (1, 2, 4, 8):
-        if n == 1:
-            topo = bands.BandTopology(0, 1, 0, hblk_total)
-        else:
-            r = n // 2
-            r0, r1 = bands.band_rows(hblk_total, n, r)
-            topo = bands.BandTopology(r, n, r0, r1)
-        src = full[topo.r0:topo.r1].contiguous()
+    delay = _device_delay(torch, stream)
+
+    def time_band(src, topo, wait_us, exchange=True):
         work = [src.clone() for _ in range(steps + 2)]
         eng = bands.HipBandEngine(hip, torch, work[0], quant, flags, luma=1, device=dev)
         h = eng.hblk * 8
+        is_band = exchange and topo.world > 1
 
         def fake_exchange():
-            if n > 1:                                    # same bytes as the real exchange, both directions
+            if is_band:                                  # same bytes as the real exchange, both directions
                 eng.row(-1).copy_(eng.row(0)); eng.row(h).copy_(eng.row(h - 1))
+                if wait_us and delay:
+                    delay(wait_us)
         pairs, pend = [], []
 
         def mark(which):
@@ -510,11 +533,31 @@ def _scaling_emulation(torch, hip, bands, full, quant, flags, niter, dev, hblk_t
             bands.run_bands_batched_sets(hip, [eng], topo, niter, fake_exchange, mark=mark if i >= 2 else None)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
+        return ms, float(np.mean([a.elapsed_time(b) for a, b in pairs])) * 1e3
+    for n in (1, 2, 4, 8):
+        if n == 1:
+            topo = bands.BandTopology(0, 1, 0, hblk_total)
+        else:
+            r = n // 2
+            r0, r1 = bands.band_rows(hblk_total, n, r)
+            topo = bands.BandTopology(r, n, r0, r1)
+        src = full[topo.r0:topo.r1].contiguous()
+        ms, pb = time_band(src, topo, 0)
         out["ms_per_step"][str(n)] = ms
-        out["pass_b_us"][str(n)] = float(np.mean([a.elapsed_time(b) for a, b in pairs])) * 1e3
-        del work, eng
+        out["pass_b_us"][str(n)] = pb
+        if n > 1:
+            if delay:
+                out["exchange_latency_us"][str(n)] = {str(d): out["ms_per_step"]["1"] / time_band(src, topo, d)[0] for d in delays[1:]}
+            r0, r1, e0, e1 = bands.deep_band_rows(hblk_total, n, n // 2, niter)
+            dms, _ = time_band(full[e0:e1].contiguous(), bands.BandTopology(0, 1, e0, e1), 0, exchange=False)
+            out["deep_halo"]["ms_per_step"][str(n)] = dms
+            out["deep_halo"]["rows"][str(n)] = [r1 - r0, e1 - e0]
+        del src
     for n in ("2", "4", "8"):
         out["speedup_vs_1"][n] = out["ms_per_step"]["1"] / out["ms_per_step"][n]
+        out["deep_halo"]["speedup_vs_1"][n] = out["ms_per_step"]["1"] / out["deep_halo"]["ms_per_step"][n]
+    if not delay:
+        out["exchange_latency_us"] = None
     return out
 
 

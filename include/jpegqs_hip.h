@@ -108,6 +108,16 @@ int qs_hip_do_quantsmooth_batch(qs_hip_job *const *jobs, int njobs, int flags, i
  * such as "0,1,2,3"; read once per process); fewer than two entries = no sharding.  An ordinal may repeat (several bands on one GPU: how the route is
  * tested on a one-GPU box).  n = 0 returns to the default. */
 int qs_hip_set_devices(const int *devices, int n);
+/* How the bands of an independent-component job (CLI --quality 3/4) keep each other exact:
+ *   0 (default)  one pixel row per band edge is exchanged after every pass A (niter small, latency-bound transfers);
+ *   1            COMMUNICATION-AVOIDING: every cut side of a band carries `niter` block rows of its neighbour and
+ *                all iterations run without any exchange -- the error made by treating the cut as an image edge
+ *                moves one block row per iteration and never reaches the rows the band owns.  Costs 2 * niter block
+ *                rows of extra work per inner band (+4.7 % at 8192 x 8192 over 8 devices, niter 3; +2.3 % at 16384^2).
+ *  -1            back to the default (the environment variable QS_HIP_SHARD_SCHEDULE=deep also selects 1).
+ * Both give the one-device result bit for bit.  Coupled YCbCr jobs (--quality 5/6) always use 0.
+ * The reference's counterpart: the OpenMP row split of quantsmooth.h:2587-2640, which shares one pixel plane. */
+int qs_hip_set_shard_schedule(int schedule);
 /* the same job, cut over exactly these devices whatever its size (QS_HIP_ENOTSUP when the
  * flag / table combination has no sharded route; a progress callback is not available here) */
 int qs_hip_do_quantsmooth_sharded(qs_hip_job *job, int flags, int niter, const int *devices, int ndev);
@@ -158,9 +168,10 @@ void qs_hip_release_cache(void);
 int qs_hip_device_count(void);
 const char *qs_hip_last_error(void);
 /* Version of this interface: bumped whenever a struct layout or the meaning of an argument changes (5: round 5 --
- * qs_hip_plane_ref back to its 48-byte form, second planes through qs_hip_smooth_planes_next).  A caller built against
+ * qs_hip_plane_ref back to its 48-byte form, second planes through qs_hip_smooth_planes_next; 6: round 6 --
+ * additions only: qs_hip_set_shard_schedule, the RCCL band entry points).  A caller built against
  * this header can compare QS_HIP_ABI_VERSION with what the loaded library reports. */
-#define QS_HIP_ABI_VERSION 5
+#define QS_HIP_ABI_VERSION 6
 int qs_hip_abi_version(void);
 
 /* bytes of the per-component constant block; pixel-plane pitch and size */

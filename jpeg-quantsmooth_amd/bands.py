@@ -69,6 +69,29 @@ def band_rows(hblk: int, world: int, rank: int, align: int = 1):
     return lib.band_rows(hblk, world, rank, align) if lib else _band_rows_py(hblk, world, rank, align)
 
 
+def deep_band_rows(hblk: int, world: int, rank: int, niter: int, align: int = 1):
+    """The COMMUNICATION-AVOIDING schedule (csrc/qs_shard.cpp: qs_hip_set_shard_schedule(1)): -> (r0, r1, e0, e1), the rows
+    [r0, r1) the rank owns and the rows [e0, e1) it holds and runs -- `niter` more block rows on every cut side (none at
+    the image edges).  Treating the cuts as image edges makes an error that travels one block row per iteration (a block
+    reads one pixel row across its border, reference quantsmooth.h:1396-1401) and therefore stops short of [r0, r1):
+    all iterations run without a single exchange.  Cost: 2 * niter extra block rows per inner band."""
+    r0, r1 = band_rows(hblk, world, rank, align)
+    return r0, r1, max(0, r0 - niter), min(hblk, r1 + niter)
+
+
+def run_band_deep(engine, niter: int) -> None:
+    """one complete smoothing of a deep-halo band (an engine built on rows [e0, e1) of deep_band_rows): both plane edges
+    replicate like image edges, nothing is exchanged; the caller keeps rows [r0 - e0, r1 - e0) of the result"""
+    if hasattr(engine, "smooth_next"):
+        engine.idct(True, 1, 1)
+        for it in range(niter):
+            engine.smooth_next(it == niter - 1, it < niter - 1, 1, 1)
+        return
+    for it in range(niter):
+        engine.idct(it == 0, 1, 1)
+        engine.smooth(it == niter - 1)
+
+
 @dataclass
 class BandTopology:
     rank: int

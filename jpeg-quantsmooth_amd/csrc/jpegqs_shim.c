@@ -389,9 +389,12 @@ boolean jpegqs_start_decompress(j_decompress_ptr cinfo, jpegqs_control_t *opts) 
 	boolean ret;
 	int use_qs = opts->niter > 0 || (opts->flags & JPEGQS_UPSAMPLE_UV);
 	if (use_qs) cinfo->buffered_image = TRUE;
-	if (use_qs) jpegqs_hip_prewarm(cinfo, opts);   /* the GPU side comes up while libjpeg reads the scans */
 	ret = jpeg_start_decompress(cinfo);
 	if (use_qs) {
+		/* the GPU side comes up while libjpeg reads the scans below (buffered-image mode: jpeg_start_decompress() has
+		 * only set the decompressor up -- and has had its chance to refuse the file, e.g. an unsupported colour
+		 * conversion, before a device is touched for it) */
+		jpegqs_hip_prewarm(cinfo, opts);
 		while (!jpeg_input_complete(cinfo)) {
 			jpeg_start_output(cinfo, cinfo->input_scan_number);
 			jpeg_finish_output(cinfo);

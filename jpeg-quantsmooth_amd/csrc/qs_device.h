@@ -55,8 +55,13 @@ enum {
   QS_REC_V_SKIP4 = 16,     // v == 4
   QS_REC_V_EVEN = 32,      // v even
   QS_REC_LDS_SHIFT = 6,    // bits 6..19: byte offset of coefficient i in a lane's LDS column, (i >> 1) * 65 * 4 + (i & 1) * 2
-  QS_REC_NXT_SHIFT = 12    // bit 20 (value 0x100 after the shift): the NEXT coefficient has no horizontal section, its
+  QS_REC_NXT_SHIFT = 12,   // bit 20 (value 0x100 after the shift): the NEXT coefficient has no horizontal section, its
                            // first weight chunk is the border chunk, 256 bytes into its row
+  QS_REC_Q1 = 1 << 21      // the coefficient's quantiser is 1 (or a damaged file's 0, treated as 1): its interval is the single
+                           // point it already holds (reference quantsmooth.h:1552-1557: d0 = d1 = 0, dl = dh = a0 = coef), so
+                           // its whole term stream cannot change anything -- the recovery kernels skip it (exact; the
+                           // reference has no such shortcut).  High-quality JPEGs: 8 of 63 luma entries at IJG quality 95,
+                           // 28 at 98.
 };
 
 static inline int qs_plane_pitch(int wblk) {

@@ -502,16 +502,31 @@ void warm_pools(std::vector<size_t> pinned, std::vector<size_t> device) {
 // HIP runtime's own static destructors run.  This library is unloaded before libamdhip64 (it depends on it), so its
 // static destructor is the place to wait for them (bounded: they finish in tens of milliseconds).
 namespace {
-struct BackgroundJoin {
-  ~BackgroundJoin() {
-    for (int i = 0; i < 5000; ++i) {
-      bool warm;
-      { std::lock_guard<std::mutex> lk(g_warm_mu); warm = g_warm_running != 0; }
-      if (!warm && !g_bg_busy.load()) return;
-      std::this_thread::sleep_for(std::chrono::milliseconds(1));
-    }
+void wait_for_background() {
+  for (int i = 0; i < 5000; ++i) {
+    bool warm;
+    { std::lock_guard<std::mutex> lk(g_warm_mu); warm = g_warm_running != 0; }
+    if (!warm && !g_bg_busy.load()) return;
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
   }
+}
+struct BackgroundJoin {
+  ~BackgroundJoin() { wait_for_background(); }
 } g_background_join;
+// That destructor is not early enough for a process that EXITS while a prewarm thread is still at work (an
+// application whose libjpeg error handler fires right after jpegqs_start_decompress() began -- the reference's
+// example.c on a CMYK file -- and returns from main()): the HIP runtime registers exit handlers of its own lazily,
+// from inside hipInit / context creation, i.e. AFTER this library's static objects, so they run BEFORE the destructor
+// above and tear the runtime down under the thread (seen on MI355X as a glibc heap-corruption abort at exit).  exit()
+// runs handlers newest first, so the wait is registered with atexit() at three points, once each per process: when the
+// first prewarm thread is started (newest while the thread is still inside hipInit), and from the thread itself right
+// after hipInit and again after the context and queues exist (newer than anything the runtime registered by then).
+void register_exit_wait(int point) {
+  static std::atomic<unsigned> done{0};
+  const unsigned bit = 1u << point;
+  if (done.fetch_or(bit) & bit) return;
+  (void)atexit(wait_for_background);
+}
 }  // namespace
 
 void qsj::warm_wait() {
@@ -556,11 +571,14 @@ extern "C" int qs_hip_prewarm(const qs_hip_job* geometry, int flags, int niter) 
       static void done() { { std::lock_guard<std::mutex> lk(g_warm_mu); --g_warm_running; } g_warm_cv.notify_all(); }
       ~WarmCount() { if (armed) done(); }
     } count;
+    register_exit_wait(0);
     std::thread([sizes, device, dev]() {
       try {
         int n = 0;
-        if (hipGetDeviceCount(&n) == hipSuccess && n > 0 && hipSetDevice(dev) == hipSuccess) {
-          if (warm_runtime_claim(dev)) warm_runtime();
+        const bool have = hipGetDeviceCount(&n) == hipSuccess && n > 0;
+        register_exit_wait(1);
+        if (have && hipSetDevice(dev) == hipSuccess) {
+          if (warm_runtime_claim(dev)) { warm_runtime(); register_exit_wait(2); }
           if (!sizes.empty()) warm_pools(sizes, device);
         } else (void)hipGetLastError();
       } catch (...) {}

@@ -15,6 +15,7 @@ enum { JOB_RERUN_CAREFUL = -1000 };   // internal result: run the job again in t
 double wall_ms();
 void warm_wait();                      // block while a qs_hip_prewarm() thread is still at work
 bool trace_on();                       // QS_HIP_TRACE=1: phase times on stderr
+bool shard_schedule_deep();            // qs_hip_set_shard_schedule / QS_HIP_SHARD_SCHEDULE: the communication-avoiding band schedule
 size_t env_size(const char* name, size_t dflt);
 
 // reference quantsmooth.h:2639 + :1567-1568: does component ci get the rebalance step

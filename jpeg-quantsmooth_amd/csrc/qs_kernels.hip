@@ -413,6 +413,9 @@ typedef int qs_i4 __attribute__((ext_vector_type(4)));         // one per-coeffi
 #define QS_HOIST_DIAG 32   /* the DIAGONALS kernel: 152 VGPRs at 20 */
 #endif
 // Column-restricted pass 1 of the refresh (qs_smooth_kernel.inc): 1 = park the pass-1 outputs of two block columns in LDS
+#ifndef QS_Q1_SKIP
+#define QS_Q1_SKIP 1   /* coefficients whose quantiser is 1 skip their term stream (QS_REC_Q1, qs_device.h): exact */
+#endif
 #ifndef QS_STASH
 #define QS_STASH 1
 #endif

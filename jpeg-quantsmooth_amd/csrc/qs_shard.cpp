@@ -21,6 +21,12 @@
 //
 // Routes: independent components (no JOINT_YUV / UPSAMPLE_UV coupling, no LOW_QUALITY; CLI
 // --quality 3/4, any colour layout) run as ONE plane set per band and pass -- run_sharded_set.
+// That route has a second, COMMUNICATION-AVOIDING schedule (qs_hip_set_shard_schedule(1) /
+// QS_HIP_SHARD_SCHEDULE=deep): a band carries `niter` extra block rows of its neighbours on each cut
+// side and runs all iterations without any exchange -- the error of treating the cut as an image edge
+// travels one block row per iteration and stops short of the rows the band owns (what the banded
+// one-device route of qs_fused.cpp does between its bands).  +2 * niter block rows of work per inner
+// band (+4.7 % at 8192^2 over 8 devices, niter 3) against niter exchanges whose cost is pure latency.
 // Coupled YCbCr jobs (--quality 5/6) are cut on chroma block rows (the luma band is the
 // v_samp-times taller range of the same image rows) and add three one-off exchanges: the
 // low-res luma plane, the refreshed chroma planes -- run_sharded_colour.
@@ -39,7 +45,11 @@ static void band_rows(int hblk, int n, int d, int& r0, int& r1) {
 }
 
 struct BandPlane {       // one component's band on one device
-  int ci = 0, wb = 0, hb = 0, r0 = 0;
+  int ci = 0, wb = 0, hb = 0, r0 = 0;    // the block rows [r0, r0 + hb) live on the device
+  int own0 = 0, own_hb = -1;             // ... of which [r0 + own0, r0 + own0 + own_hb) are the band's own (written back);
+                                         // -1: all of them (the exchange schedule); fewer with the deep-halo schedule
+  int own_rows() const { return own_hb < 0 ? hb : own_hb; }
+  size_t own_off() const { return coef_off + (size_t)own0 * wb * 128; }   // arena offset of the first owned row
   bool halo_top = false, halo_bot = false;
   size_t coef_off = 0, px_off = 0, cbytes = 0;
   int cst = -1;
@@ -272,7 +282,7 @@ static void restore_bands(Bands& bands, const qs_hip_job* job) {
     (void)hipStreamSynchronize(B.s);
     if (!B.stage.p) continue;
     std::vector<Piece> pcs;
-    for (const BandPlane& P : B.planes) host_pieces(job, P.ci, P.r0, P.hb, P.coef_off, pcs);
+    for (const BandPlane& P : B.planes) host_pieces(job, P.ci, P.r0 + P.own0, P.own_rows(), P.own_off(), pcs);   // (only these are ever written)
     for (const Piece& pc : pcs) memcpy(pc.host, static_cast<const char*>(B.stage.p) + pc.off, pc.len);
   }
 }
@@ -303,6 +313,15 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
 
   // every component is cut into min(n, hblk / 8) bands (a band keeps at least 8 block rows),
   // which go to the first devices of the list
+  // deep: the communication-avoiding schedule (see the top of this file) -- every cut side of a band carries niter
+  // block rows of the neighbouring band, both plane edges replicate like image edges, nothing is exchanged
+  // (only while the extra rows stay a fraction of a band: 4 * niter <= the shortest band; beyond that -- tiny images, or
+  //  niter in the dozens -- the exchange schedule is the cheaper one)
+  bool deep = shard_schedule_deep();
+  for (int ci = 0; ci < job->ncomp && deep; ++ci) {
+    const int nb = std::max(1, std::min(n, job->hblk[ci] / 8));
+    if (nb > 1 && job->hblk[ci] / nb < 4 * niter) deep = false;
+  }
   for (int ci = 0; ci < job->ncomp; ++ci) {
     const int hb = job->hblk[ci];
     const int nb = std::max(1, std::min(n, hb / 8));
@@ -312,6 +331,12 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
       band_rows(hb, nb, d, r0, r1);
       P.ci = ci; P.wb = job->wblk[ci]; P.hb = r1 - r0; P.r0 = r0;
       P.halo_top = d > 0; P.halo_bot = d < nb - 1;
+      if (deep) {
+        const int e0 = std::max(0, r0 - niter), e1 = std::min(hb, r1 + niter);
+        P.own0 = r0 - e0; P.own_hb = r1 - r0;
+        P.r0 = e0; P.hb = e1 - e0;
+        P.halo_top = P.halo_bot = false;                     // the cut is treated as an image edge (replicated)
+      }
       bands.b[d].planes.push_back(P);
     }
   }
@@ -339,6 +364,7 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
         qs_launch_idct_set(B.set, 1, B.s);
       }
     // one pixel row per component and band edge, of the planes this iteration's pass B reads
+    if (!deep)
     if (int r = exchange(bands, job->ncomp, [&](int d, int ci, uint8_t** p, int* wb, int* hb) {
           const BandPlane* P = find_plane(bands.b[d], ci);
           if (!P) return false;
@@ -408,7 +434,7 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
     HIP_TRY_RESTORE(hipSetDevice(B.dev));
     std::vector<Piece> back;
     for (const BandPlane& P : B.planes)
-      host_pieces(job, P.ci, P.r0, P.hb, P.coef_off, back);
+      host_pieces(job, P.ci, P.r0 + P.own0, P.own_rows(), P.own_off(), back);
     HIP_TRY_RESTORE(B.down.finish(B.coef.p, back, B.s, B.stage.p != nullptr));
   }
   if (trace_on()) {
@@ -424,8 +450,9 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
       }
     }
     fprintf(stderr, "qs_hip trace: sharded(set) %d band(s)  upload+stage %.2f ms  enqueue %.2f ms  drain+scatter %.2f ms  "
-                    "iterations on device: max %.2f ms (per band:%s)%s\n",
-            n, t_up - t_start, t_enq - t_up, wall_ms() - t_enq, worst, per.c_str(), plan ? "  progress: callback served from this route" : "");
+                    "iterations on device: max %.2f ms (per band:%s)%s%s\n",
+            n, t_up - t_start, t_enq - t_up, wall_ms() - t_enq, worst, per.c_str(), plan ? "  progress: callback served from this route" : "",
+            deep ? "  schedule: deep halo, no exchange" : "  schedule: one halo row per iteration");
   }
   for (int ci = 0; ci < job->ncomp; ++ci)                    // reference :2851-2859
     if (job->has_quant[ci]) for (int i = 0; i < 64; ++i) job->quant[ci][i] = 1;
@@ -751,6 +778,20 @@ int qsj::run_sharded(qs_hip_job* job, int flags, int niter, const std::vector<in
   if (job_fusable(job, flags)) return run_sharded_set(job, flags, niter, devices, plan);
   if (colour_shardable(job, flags, niter)) return run_sharded_colour(job, flags, niter, devices);
   return qs_fail(QS_HIP_ENOTSUP, "sharded job: this flag / table combination runs on one device");
+}
+
+// schedule of the independent-component route: -1 = not set by the API (the environment decides)
+static std::atomic<int> g_shard_schedule{-1};
+bool qsj::shard_schedule_deep() {
+  const int v = g_shard_schedule.load();
+  if (v >= 0) return v == 1;
+  const char* e = getenv("QS_HIP_SHARD_SCHEDULE");
+  return e && (!strcmp(e, "deep") || !strcmp(e, "1"));
+}
+extern "C" int qs_hip_set_shard_schedule(int schedule) {
+  if (schedule < -1 || schedule > 1) return qs_fail(QS_HIP_EINVAL, "qs_hip_set_shard_schedule: 0 = halo row per iteration, 1 = deep halo, -1 = default");
+  g_shard_schedule.store(schedule);
+  return QS_HIP_OK;
 }
 
 extern "C" int qs_hip_set_devices(const int* devices, int n) {

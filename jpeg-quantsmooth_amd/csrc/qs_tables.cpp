@@ -198,6 +198,7 @@ extern "C" int qs_hip_consts_build(void* host_out, const uint16_t quant[64], int
       if (!(v & 1)) m |= QS_REC_V_EVEN;
       m |= ((i >> 1) * QS_LDS_PITCH * 4 + (i & 1) * 2) << QS_REC_LDS_SHIFT;
       if (!(i_nxt & 7)) m |= 0x100 << QS_REC_NXT_SHIFT;
+      if (c->q[k] == 1) m |= QS_REC_Q1;
       c->rec[k][3] = m;
     }
   }

@@ -89,6 +89,7 @@ ABI = {
     "qs_hip_do_quantsmooth_rows": (C.c_int, [C.POINTER(Job), C.POINTER(C.POINTER(C.c_void_p)), C.c_int, C.c_int, C.c_int,
                                           PROGRESS_FN, C.c_void_p]),
     "qs_hip_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "qs_hip_set_shard_schedule": (C.c_int, [C.c_int]),
     "qs_hip_do_quantsmooth_sharded": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "qs_hip_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "qs_hip_colour_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4),
@@ -295,6 +296,10 @@ class HipQS:
         """qs_hip_set_devices: the device list large jobs are spread over ([] = default)"""
         arr = (C.c_int * max(1, len(devices)))(*devices)
         self._check(self.lib.qs_hip_set_devices(arr, len(devices)))
+
+    def set_shard_schedule(self, schedule: int):
+        """qs_hip_set_shard_schedule: 0 = one halo row per iteration, 1 = deep halo (no exchange), -1 = default"""
+        self._check(self.lib.qs_hip_set_shard_schedule(schedule))
 
     def do_quantsmooth_batch(self, jobs, flags, niter):
         """qs_hip_do_quantsmooth_batch: `jobs` = list of dicts with the keyword

@@ -79,8 +79,32 @@ def main():
     save("ycc420_104x72_extreme_q5_n1", ref, j["coefs"], j["quants"], 3, 1, **kw)
 
 
+def make_highq_golden():
+    """High-quality JPEGs (IJG quality 92 / 95 / 98): many quantiser entries are 1 there (0 / 8 / 28 of luma's 63 AC
+    entries) -- the coefficients the recovery kernels skip (QS_REC_Q1, csrc/qs_device.h), because the reference's
+    interval for them is a single point.  Outputs of the compiled reference, like everything else here."""
+    assert build_ref(), "/root/reference must be mounted to regenerate golden vectors"
+    ref = Reference("none")
+    synth = jpegqs_pkg.load().synth
+    for jq in (92, 95, 98):
+        coef, quant = synth.synth_gray(120, 88, jq, seed=jq)
+        print("quality", jq, "luma entries equal to 1:", int((quant[1:] == 1).sum()))
+        save(f"gray120x88_jq{jq}_q3_n3", ref, [coef], [quant], 0, 3)
+        save(f"gray120x88_jq{jq}_q4_n2", ref, [coef], [quant], 1, 2)
+    coef, quant = synth.synth_gray(120, 88, 98, seed=98)
+    save("gray120x88_jq98_q3_norebalance_n2", ref, [coef], [quant], 16, 2)
+    for jq in (95, 98):
+        j = synth.synth_ycc(104, 72, 2, 2, quality=jq, seed=jq)
+        kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(104, 72))
+        save(f"ycc420_104x72_jq{jq}_q6_n2", ref, j["coefs"], j["quants"], 7, 2, **kw)
+        save(f"ycc420_104x72_jq{jq}_q3_n2", ref, j["coefs"], j["quants"], 0, 2, **kw)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "highq":
+        make_highq_golden()
+    else:
+        main()
 
 
 CLI_OPTION_CASES = [("f33", ["-f", "33", "-n", "2"]), ("f20_n1", ["--flags", "20", "--niter", "1"]),

@@ -83,6 +83,55 @@ def test_bands_gloo_equal_unsharded(world, overlapped, flags, oracle, synth, tmp
     assert np.array_equal(got, want)
 
 
+def _deep_worker(rank, world, port, flags, niter, tmp):
+    """one rank of the communication-avoiding schedule: holds niter extra block rows per cut side, exchanges NOTHING
+    during the iterations (the process group only carries the final barrier)"""
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    import torch
+    import torch.distributed as dist
+    import jpegqs_pkg
+    from oracle.oracle import Oracle
+    from band_cpu_engine import OracleBandEngine
+    pkg = jpegqs_pkg.load()
+    from jpeg_quantsmooth_amd import bands
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    coef, quant = pkg.synth.synth_gray(136, 520, 45, seed=21)     # 65 x 17 blocks
+    r0, r1, e0, e1 = bands.deep_band_rows(coef.shape[0], world, rank, niter)
+    eng = OracleBandEngine(Oracle(), pkg.HipQS(), coef[e0:e1].copy(), quant, flags)
+    if rank & 1:
+        del OracleBandEngine.smooth_next                             # odd ranks: the unfused loop of run_band_deep
+    bands.run_band_deep(eng, niter)
+    assert not eng.bad_coef()
+    np.save(os.path.join(tmp, f"band{rank}.npy"), eng.coef[r0 - e0:r1 - e0])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,niter", [(2, 3), (3, 2), (4, 5), (8, 1)])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_deep_halo_bands_gloo_equal_unsharded(world, niter, flags, oracle, synth, tmp_path):
+    """world_size > 1, CPU, gloo: the communication-avoiding schedule (bands.deep_band_rows / run_band_deep, the
+    one-process-per-GPU form of qs_hip_set_shard_schedule(1)) reproduces the unsharded result bit for bit with ZERO halo
+    exchanges -- niter extra block rows per cut side absorb the error of treating the cuts as image edges"""
+    import torch.multiprocessing as mp
+    mp.spawn(_deep_worker, args=(world, _free_port(), flags, niter, str(tmp_path)), nprocs=world, join=True)
+    coef, quant = synth.synth_gray(136, 520, 45, seed=21)
+    want = oracle.do_quantsmooth([coef], [quant], flags, niter)["coefs"][0]
+    got = np.concatenate([np.load(tmp_path / f"band{r}.npy") for r in range(world)], axis=0)
+    assert np.array_equal(got, want)
+
+
+def test_deep_band_rows_arithmetic(pkg):
+    from jpeg_quantsmooth_amd import bands
+    for hblk, world, niter in ((128, 8, 3), (65, 4, 5), (1024, 8, 3), (17, 2, 20)):
+        for rank in range(world):
+            r0, r1, e0, e1 = bands.deep_band_rows(hblk, world, rank, niter)
+            assert (r0, r1) == bands.band_rows(hblk, world, rank)
+            assert e0 == max(0, r0 - niter) and e1 == min(hblk, r1 + niter) and e0 <= r0 <= r1 <= e1
+
+
 def _batched_worker(rank, world, port, tmp, packed=False):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
     import torch
@@ -314,6 +363,28 @@ def test_fused_bands_on_one_gpu_equal_unsharded(gpu, pkg, oracle, synth, nbands,
         got = np.concatenate([e.coef.cpu().numpy() for e in engines], axis=0)
         want = oracle.do_quantsmooth([coef], [quant], flags, niter, threads=8)["coefs"][0]
         assert np.array_equal(got, want), f"flags={flags}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbands", [2, 8])
+def test_deep_halo_bands_on_one_gpu_equal_unsharded(gpu, pkg, oracle, synth, nbands):
+    """the communication-avoiding band schedule through HipBandEngine (bands.run_band_deep) with N logical bands on one
+    device: no halo row moves, every band runs niter extra block rows per cut side -- bit-exact against the unsharded oracle"""
+    import torch
+    from jpeg_quantsmooth_amd import bands
+    coef, quant = synth.synth_gray(520, 1040, 50, seed=4)
+    hblk = coef.shape[0]
+    dev = torch.device("cuda:0")
+    for flags, niter in ((0, 3), (1, 2), (0, 5)):
+        parts = []
+        for r in range(nbands):
+            r0, r1, e0, e1 = bands.deep_band_rows(hblk, nbands, r, niter)
+            eng = bands.HipBandEngine(gpu, torch, torch.from_numpy(coef[e0:e1].copy()).to(dev), quant, flags)
+            bands.run_band_deep(eng, niter)
+            assert not eng.bad_coef()
+            parts.append(eng.coef[r0 - e0:r1 - e0].cpu().numpy())
+        want = oracle.do_quantsmooth([coef], [quant], flags, niter, threads=8)["coefs"][0]
+        assert np.array_equal(np.concatenate(parts, axis=0), want), f"flags={flags} niter={niter}"
 
 
 @pytest.mark.gpu

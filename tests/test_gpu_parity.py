@@ -573,7 +573,7 @@ def test_gpu_fuzz_corpus():
     assert "400 trials, 959 jobs" in r.stdout and " 0 failures" in r.stdout
 
 
-def _run_py(code, env_extra, timeout=900):
+def _run_py(code, env_extra, timeout=900, with_stderr=False):
     import os
     import subprocess
     import sys
@@ -582,7 +582,7 @@ def _run_py(code, env_extra, timeout=900):
     env = dict(os.environ, **env_extra)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout, cwd=str(root), env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    return r.stdout
+    return r.stdout + r.stderr if with_stderr else r.stdout
 
 
 _BAND_ENV = {"QS_HIP_SPLIT_BLOCKS": "60", "QS_HIP_BAND_BLOCKS": "40"}

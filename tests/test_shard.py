@@ -31,6 +31,56 @@ def test_sharded_gray_equals_unsharded(gpu, oracle, synth, nbands):
         assert_same_result(got, want, f"gray {nbands} bands flags={flags}")
 
 
+def test_shard_schedule_setter(hip):
+    """no GPU needed: qs_hip_set_shard_schedule validates its argument"""
+    assert hip.lib.qs_hip_set_shard_schedule(2) == -2 and hip.lib.qs_hip_set_shard_schedule(-2) == -2
+    for v in (1, 0, -1):
+        assert hip.lib.qs_hip_set_shard_schedule(v) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbands", [2, 3, 5, 8])
+def test_sharded_deep_halo_schedule_equals_unsharded(gpu, oracle, synth, nbands):
+    """the COMMUNICATION-AVOIDING schedule (qs_hip_set_shard_schedule(1)): every cut side of a band carries niter block
+    rows of its neighbour, no halo exchange at all -- the same coefficients as the unsharded run, for gray and for
+    independent YCbCr components (each cut on its own rows), with the row-pointer entry point's in-place write-back
+    limited to the rows a band owns; niter too large for the bands falls back to the exchange schedule"""
+    coef, quant = synth.synth_gray(264, 1040, 50, seed=4)       # 130 x 33 blocks
+    j = synth.synth_ycc(333, 777, 2, 2, quality=45, seed=9)
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(333, 777))
+    gpu.set_shard_schedule(1)
+    try:
+        for flags, niter in ((0, 3), (1, 2), (16, 1), (0, 5), (1, 40)):
+            want = oracle.do_quantsmooth([coef], [quant], flags, min(niter, 6))
+            got = gpu.do_quantsmooth([coef], [quant], flags, min(niter, 6), devices=[0] * nbands)
+            assert_same_result(got, want, f"gray deep halo {nbands} bands flags={flags} niter={niter}")
+        for flags, niter in ((0, 3), (1, 2), (32, 2)):
+            want = oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+            got = gpu.do_quantsmooth(j["coefs"], j["quants"], flags, niter, devices=[0] * nbands, **kw)
+            assert_same_result(got, want, f"ycc deep halo {nbands} bands flags={flags}")
+        # coupled flags keep their own schedule (one-off exchanges), whatever is selected here
+        want = oracle.do_quantsmooth(j["coefs"], j["quants"], 7, 2, **kw)
+        assert_same_result(gpu.do_quantsmooth(j["coefs"], j["quants"], 7, 2, devices=[0] * min(nbands, 4), **kw), want, "q6 with deep selected")
+        # a tripped range check in a halo copy of a block is still the job's range check
+        job, wantb = load_golden("gray64_badcoef_q3_n2")
+        assert_same_result(gpu.do_quantsmooth(job["coefs"], job["quants"], job["flags"], job["niter"], devices=[0, 0], **job["kw"]), wantb, "bad coefficient")
+    finally:
+        gpu.set_shard_schedule(-1)
+
+
+@pytest.mark.gpu
+def test_sharded_deep_halo_transparent_route_and_trace(gpu):
+    """QS_HIP_SHARD_SCHEDULE=deep in the environment: the fuzz corpus through qs_hip_do_quantsmooth with three logical
+    devices, every shardable job on the deep-halo schedule (the trace line says which one ran)"""
+    from test_gpu_parity import _run_py
+    out = _run_py("import runpy, sys; sys.argv = ['fuzz_gpu.py', 'run', 'tests/golden/fuzz_s2.jsonl']; "
+                  "runpy.run_path('tools/fuzz_gpu.py', run_name='__main__')",
+                  {"QS_HIP_DEVICES": "0,0,0", "QS_HIP_SHARD_MIN_BLOCKS": "1", "QS_HIP_TRACE": "1", "QS_HIP_SHARD_SCHEDULE": "deep"},
+                  with_stderr=True)
+    assert "400 trials, 959 jobs" in out and " 0 failures" in out
+    assert "schedule: deep halo, no exchange" in out
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("size,samp", [((256, 160), (2, 2)), ((333, 517), (2, 2)), ((321, 200), (1, 1)),
                                        ((208, 328), (2, 1)), ((200, 264), (1, 2)), ((320, 264), (4, 1))])

@@ -20,13 +20,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--flags", type=int, default=0)
 ap.add_argument("--rows", default="1,8,16,32,48,64,96,112,128,144,160,192,256,384,512,1024")
 ap.add_argument("--smooth", action="store_true", help="the smooth variant of the synthetic image (periods x10, no noise)")
+ap.add_argument("--jpeg-quality", type=int, default=50, help="IJG quality the synthetic plane is encoded at (95 / 98: quantiser entries equal to 1, which the kernels skip)")
 ap.add_argument("libs", nargs="*")
 args = ap.parse_args()
 pkg = jpegqs_pkg.load()
 flags = args.flags
 libs = [Path(p) for p in args.libs] or [pkg.lib_path()]
 dev = torch.device("cuda:0")
-full, quant = bench.synth_input_gpu(torch, pkg, 8192, 50, dev, smooth=args.smooth)
+full, quant = bench.synth_input_gpu(torch, pkg, 8192, args.jpeg_quality, dev, smooth=args.smooth)
+print("JPEG quality", args.jpeg_quality, ": AC quantiser entries equal to 1:", int((quant[1:] == 1).sum()), "of 63")
 wb = 1024
 rows = [int(r) for r in args.rows.replace("+", ",").split(",")]
 print("flags", flags, "rows:", rows)
