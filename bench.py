@@ -48,6 +48,10 @@ Extra legs of the luma workload (not part of `value`; `--no-extras` skips them):
                                    strong scaling (N > 1: the RCCL halo exchange is paid per plane)
   scaling_emulation                N = 1: one rank's share of a SINGLE-image run on 2 / 4 / 8 GPUs emulated on this GPU (the
                                    middle 1/N band of one plane, halo rows as device copies): ms per step, pass-B launch time, speed-up
+                                   -- also with 25 / 50 / 100 us of injected exchange latency, and for the communication-avoiding
+                                   schedule (niter extra block rows per cut side, no exchange)
+  deep_halo_schedule               N > 1: the single image on the communication-avoiding schedule, timed like value_batch1; its owned
+                                   rows must equal the exchange schedule's
   smooth_input                     N = 1: the same workload on the smooth variant of the image (periods x10, no noise),
                                    where the wave-uniform need_refresh skip applies
   product_route                    the PRODUCT's own multi-GPU route over the same N devices -- qs_hip_do_quantsmooth_sharded
@@ -439,7 +443,7 @@ def main():
                               "flop_per_block_iter": FLOP_PER_BLOCK_ITER[flags & 1],
                               **_sustained(achieved_tf)},
         }
-        for k in ("single_plane_ms", "value_batch1", "planes_identical", "smooth_input", "scaling_emulation", "product_route", "verify_against"):
+        for k in ("single_plane_ms", "value_batch1", "planes_identical", "smooth_input", "scaling_emulation", "deep_halo_schedule", "product_route", "verify_against"):
             if res.get(k) is not None:
                 out[k] = res[k]
         for k in ("verify_ok", "verify_rows", "verify_detail", "verify_band_edges_ok"):
@@ -596,6 +600,9 @@ def run_luma(c):
             lo, hi = max(0, edge - 2 - m), min(hblk_total, edge + 2 + m)
             edge_checks.append((lo, mine, full[lo:hi].contiguous().cpu().numpy()))
     keep_full = full if (rank == 0 and (c["verify"] or not args.no_cpu_baseline)) else None
+    # N > 1 extra leg: the communication-avoiding schedule (niter extra block rows per cut side, no exchange)
+    deep_rows = bands.deep_band_rows(hblk_total, world, rank, args.niter) if (c["sharded"] and not args.no_extras) else None
+    deep_src = full[deep_rows[2]:deep_rows[3]].contiguous() if deep_rows else None
     del full
 
     work = [[pristine.clone() for _ in range(batch)] for _ in range(nsteps)]   # resident inputs, one set per step
@@ -679,7 +686,7 @@ def run_luma(c):
     planes_identical = all(bool(torch.equal(work[-1][0], p)) for p in work[-1][1:])
 
     # ---- extra legs (not part of `value`) ------------------------------------------------------------------
-    single_plane_ms = value_batch1 = smooth_res = None
+    single_plane_ms = value_batch1 = smooth_res = deep_res = None
     if engs and not args.no_extras:
         # (1) ONE plane per step (batch = 1): the latency of a single image and, for N > 1, single-image strong scaling
         k1 = max(3, min(args.steps, 20))
@@ -701,6 +708,33 @@ def run_luma(c):
         value_batch1 = total_blocks_plane / (e1 / k1)
         planes_identical = planes_identical and bool(torch.equal(w1[-1], last))
         del w1
+        # (1b) N > 1: the same single image on the COMMUNICATION-AVOIDING schedule: every rank runs its band plus niter block
+        # rows per cut side, nothing is exchanged during the iterations (csrc/qs_shard.cpp: qs_hip_set_shard_schedule(1));
+        # its owned rows must equal what the exchange schedule produced
+        if deep_src is not None and world > 1:
+            _r0, _r1, e0, e1 = deep_rows
+            wd = [deep_src.clone() for _ in range(k1 + 2)]
+            deng = bands.HipBandEngine(hip, torch, wd[0], quant, flags, luma=1, device=dev)
+            dtopo = bands.BandTopology(0, 1, e0, e1)
+
+            def one_deep(p):
+                deng.rebind(p)
+                bands.run_bands_batched_sets(hip, [deng], dtopo, args.niter, lambda: None)
+            for p in wd[:2]:
+                one_deep(p)
+            _fence(torch, dist, world)
+            td = time.perf_counter()
+            for p in wd[2:]:
+                one_deep(p)
+            _fence(torch, dist, world)
+            ed = _max_over_ranks(torch, dist, world, time.perf_counter() - td, dev, args.backend)
+            same = bool(torch.equal(wd[-1][_r0 - e0:_r1 - e0], last))
+            flag = torch.tensor([int(same)], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            deep_res = {"single_plane_ms": ed / k1 * 1e3, "value_batch1": total_blocks_plane / (ed / k1),
+                        "rows_owned_and_held": [_r1 - _r0, e1 - e0], "equals_exchange_schedule": bool(flag.item()),
+                        "what": "one image per step, every rank holds niter extra block rows per cut side and exchanges nothing"}
+            del wd, deng
         # (2) N = 1: the same workload on the smooth variant of the image (what the wave-uniform need_refresh skip is
         # worth on content that is not sensor noise; the headline input never lets a whole wave skip)
         if world == 1 and args.input == "survey":
@@ -737,7 +771,7 @@ def run_luma(c):
                kernel_launches=len(ev_pairs),
                workload=f"{size}x{size} luma plane ({hblk_total * wblk} blocks)",
                planes_identical=planes_identical, single_plane_ms=single_plane_ms, value_batch1=value_batch1,
-               smooth_input=smooth_res, scaling_emulation=scaling_emu)
+               smooth_input=smooth_res, scaling_emulation=scaling_emu, deep_halo_schedule=deep_res)
     if c["verify"] and c["sharded"]:
         from oracle.oracle import Oracle
         got = last.cpu().numpy()

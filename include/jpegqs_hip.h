@@ -122,6 +122,24 @@ int qs_hip_set_shard_schedule(int schedule);
  * flag / table combination has no sharded route; a progress callback is not available here) */
 int qs_hip_do_quantsmooth_sharded(qs_hip_job *job, int flags, int niter, const int *devices, int ndev);
 
+/* ---- several GPUs, ONE PROCESS PER GPU: the halo rows travel through RCCL ----
+ * `job` is THIS rank's band: for every component the block rows the rank owns (hblk[ci] = rows of the band, cut with
+ * qs_hip_band_rows so that the ranks' bands tile the image from top = rank 0 to bottom = rank nranks - 1), quant tables
+ * and geometry as for qs_hip_do_quantsmooth.  After pass A and between the iterations the band sends its first / last
+ * pixel row per component to rank - 1 / rank + 1 and receives theirs into its apron rows -- one ncclGroupStart /
+ * ncclSend / ncclRecv (<= 4 per component) / ncclGroupEnd per iteration on the band's stream, no host synchronisation.
+ * nccl_comm: the caller's ncclComm_t (RCCL), ranks numbered in band order; may be NULL when nranks == 1.  The library
+ * does not link librccl: it uses the copy already loaded in the caller's process.
+ * Independent components only (CLI --quality 3/4; QS_HIP_ENOTSUP otherwise), no progress callback.
+ * Returns 0, a negative QS_HIP_E* code, or QS_HIP_BAND_RANGE_CHECK when a coefficient failed the reference's range check
+ * on SOME rank (the flag is all-reduced): then no rank has written anything, and the image has to go through
+ * qs_hip_do_quantsmooth as a whole, which applies the reference's stop semantics (quantsmooth.h:2599-2610).
+ * The reference's counterpart is the OpenMP row split of quantsmooth.h:2587-2640, whose threads share the pixel plane.
+ * (The communication-avoiding alternative needs no entry point: hand qs_hip_do_quantsmooth a band extended by niter
+ *  block rows per cut side and keep the owned rows -- jpeg-quantsmooth_amd/bands.py: deep_band_rows.) */
+#define QS_HIP_BAND_RANGE_CHECK 2
+int qs_hip_do_quantsmooth_band(qs_hip_job *job, int flags, int niter, int rank, int nranks, void *nccl_comm);
+
 /* The band arithmetic itself -- ONE definition, used by the in-process route above (csrc/qs_shard.cpp: halo rows
  * pulled with hipMemcpyPeerAsync) and by the one-process-per-GPU driver (bands.py: the same rows sent with RCCL):
  * block rows [*row0, *row1) of band `band` of `nbands` (edges on multiples of `align` block rows);

@@ -317,6 +317,9 @@ static void recover_lanes(const term_table *tt, const uint16_t *q, int16_t *cons
 		vf a2 = {0}, a3 = {0}, quot;
 		int t;
 		if (stale && enters_antidiagonal(k)) { idct_lanes(c, pix); stale = 0; }
+		/* quantiser 1: the interval below is the single point the coefficient holds, nothing can change (the GPU
+		 * kernels skip these too, QS_REC_Q1 in qs_device.h).  After the refresh: that belongs to the anti-diagonal. */
+		if (q[i] == 1) continue;
 		for (t = 0; t < n; t++) {                        /* reference :1519-1520, one block per lane */
 			vf d = pix[own[t]] - pix[other[t]];
 			vf m = range - (vf)((vi)d & 0x7fffffff);

@@ -32,6 +32,9 @@
 // low-res luma plane, the refreshed chroma planes -- run_sharded_colour.
 #include <string>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library does not link librccl (see qs_hip_do_quantsmooth_band)
+
 #include "qs_jobint.h"
 
 using namespace qsx;
@@ -768,6 +771,127 @@ std::vector<int> qsj::shard_devices_for(const qs_hip_job* job, int flags, int ni
   if (blocks < min_blocks) return {};
   if (!(job_fusable(job, flags) || colour_shardable(job, flags, niter))) return {};
   return devs;
+}
+
+// ---------------------------------------------------------------------------
+// One band per PROCESS: the halo rows travel through RCCL ("ncclGroupStart; ncclSend / ncclRecv
+// x <= 2; ncclGroupEnd" between the iterations).  The library does not link librccl: the caller, who created the
+// communicator, has it loaded; its five entry points are looked up in that copy (dlopen with RTLD_NOLOAD first).
+namespace {
+struct Rccl {
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+const Rccl& rccl() {
+  static const Rccl r = [] {
+    Rccl x;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);              // the copy the caller's communicator lives in
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (!h) return x;
+    x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    x.Send = reinterpret_cast<decltype(x.Send)>(dlsym(h, "ncclSend"));
+    x.Recv = reinterpret_cast<decltype(x.Recv)>(dlsym(h, "ncclRecv"));
+    x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    x.ok = x.GroupStart && x.GroupEnd && x.Send && x.Recv && x.AllReduce;
+    return x;
+  }();
+  return r;
+}
+#define RCCL_TRY(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) \
+  return qs_fail(QS_HIP_ENODEV, "%s failed: %s", #expr, R.GetErrorString ? R.GetErrorString(r_) : "RCCL error"); } while (0)
+}  // namespace
+
+extern "C" int qs_hip_do_quantsmooth_band(qs_hip_job* job, int flags, int niter, int rank, int nranks, void* nccl_comm) {
+  if (!job || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !nccl_comm))
+    return qs_fail(QS_HIP_EINVAL, "qs_hip_do_quantsmooth_band: bad rank / communicator");
+  RowScope rows(nullptr);
+  const int todo = prepare_job(job, flags, &niter);
+  if (todo <= 0) return todo;
+  if (!job_fusable(job, flags))
+    return qs_fail(QS_HIP_ENOTSUP, "qs_hip_do_quantsmooth_band: independent components only (no JOINT_YUV / UPSAMPLE_UV / LOW_QUALITY, ordinary tables)");
+  warm_wait();
+  if (qs_hip_device_count() <= 0) return qs_fail(QS_HIP_ENODEV, "no HIP device available (this library has no CPU fallback)");
+  const Rccl& R = rccl();
+  if (nranks > 1 && !R.ok) return qs_fail(QS_HIP_ENODEV, "qs_hip_do_quantsmooth_band: librccl.so.1 is not loadable");
+  const ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+
+  struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{current_device()};
+  Bands bands(1);
+  if (int r = open_bands(bands, std::vector<int>{current_device()})) return r;
+  Band& B = bands.b[0];
+  for (int ci = 0; ci < job->ncomp; ++ci) {                  // the job IS the band: every component's rows of this rank
+    BandPlane P;
+    P.ci = ci; P.wb = job->wblk[ci]; P.hb = job->hblk[ci]; P.r0 = 0;
+    P.halo_top = rank > 0; P.halo_bot = rank < nranks - 1;
+    B.planes.push_back(P);
+  }
+  if (int r = stage_band(B, job, flags)) return r;
+  const int diag = (flags & QS_DIAGONALS) != 0;
+  const int np = (int)B.planes.size();
+  for (int it = 0; it < niter; ++it) {
+    const int cur = it & 1;
+    if (it == 0) qs_launch_idct_set(B.set, 1, B.s);
+    for (int i = 0; i < np; ++i) {
+      uint8_t* a = B.px.as<uint8_t>() + B.planes[i].px_off;
+      uint8_t* b = a + plane_stride(B.planes[i].wb, B.planes[i].hb);
+      B.set.ref[i].plane = cur ? b : a;
+      B.set.ref[i].plane_next = it == niter - 1 ? nullptr : cur ? a : b;
+    }
+    if (nranks > 1) {
+      // the exchange of reference-equivalent data: one pixel row per component and band edge, of the planes the coming
+      // pass B reads; all sends and receives of the iteration in ONE group on the band's stream
+      RCCL_TRY(R.GroupStart());
+      for (int i = 0; i < np; ++i) {
+        size_t send_top, send_bot, recv_top, recv_bot, pitch;
+        (void)qs_hip_band_halo_rows(B.planes[i].wb, B.planes[i].hb, &send_top, &send_bot, &recv_top, &recv_bot, &pitch);
+        uint8_t* p = B.set.ref[i].plane;
+        if (rank > 0) {
+          RCCL_TRY(R.Send(p + send_top, pitch, ncclUint8, rank - 1, comm, B.s));
+          RCCL_TRY(R.Recv(p + recv_top, pitch, ncclUint8, rank - 1, comm, B.s));
+        }
+        if (rank < nranks - 1) {
+          RCCL_TRY(R.Send(p + send_bot, pitch, ncclUint8, rank + 1, comm, B.s));
+          RCCL_TRY(R.Recv(p + recv_bot, pitch, ncclUint8, rank + 1, comm, B.s));
+        }
+      }
+      RCCL_TRY(R.GroupEnd());
+    }
+    qs_launch_smooth_set(B.set, diag, it == niter - 1, B.s);
+  }
+  HIP_TRY(hipGetLastError());
+  // the range check is the JOB's: any rank's tripped flag is everybody's (reference :2599-2610)
+  if (nranks > 1) RCCL_TRY(R.AllReduce(B.status.p, B.status.p, (size_t)np, ncclInt32, ncclMax, comm, B.s));
+  if (!B.hstatus.alloc((size_t)np * sizeof(int32_t))) return qs_fail(QS_HIP_ENOMEM, "out of pinned host memory");
+  HIP_TRY(hipMemcpyAsync(B.hstatus.p, B.status.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, B.s));
+  size_t coef_bytes = 0;
+  for (const BandPlane& P : B.planes) coef_bytes += P.cbytes;
+  HIP_TRY(B.down.issue(B.coef.p, coef_bytes, B.s, false));
+  bool bad = false;
+  if (int r = read_flags(bands, bad)) return r;
+  if (bad) {                                                 // nothing was written on any rank
+    HIP_TRY(hipStreamSynchronize(B.s));
+    return QS_HIP_BAND_RANGE_CHECK;
+  }
+  if (int r = land_all_if_no_copy(bands, false)) return r;
+  {
+    std::vector<Piece> back;
+    for (const BandPlane& P : B.planes) host_pieces(job, P.ci, 0, P.hb, P.coef_off, back);
+    HIP_TRY_RESTORE(B.down.finish(B.coef.p, back, B.s, B.stage.p != nullptr));
+  }
+  for (int ci = 0; ci < job->ncomp; ++ci)                    // reference :2851-2859
+    if (job->has_quant[ci]) for (int i = 0; i < 64; ++i) job->quant[ci][i] = 1;
+  return 0;
 }
 
 int qsj::run_sharded(qs_hip_job* job, int flags, int niter, const std::vector<int>& devices, ProgressPlan* plan) {

@@ -90,6 +90,7 @@ ABI = {
                                           PROGRESS_FN, C.c_void_p]),
     "qs_hip_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "qs_hip_set_shard_schedule": (C.c_int, [C.c_int]),
+    "qs_hip_do_quantsmooth_band": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "qs_hip_do_quantsmooth_sharded": (C.c_int, [C.POINTER(Job), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "qs_hip_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "qs_hip_colour_band_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4),
@@ -296,6 +297,12 @@ class HipQS:
         """qs_hip_set_devices: the device list large jobs are spread over ([] = default)"""
         arr = (C.c_int * max(1, len(devices)))(*devices)
         self._check(self.lib.qs_hip_set_devices(arr, len(devices)))
+
+    def do_quantsmooth_band(self, coefs, quants, flags, niter, rank, nranks, comm=None, **kw):
+        """qs_hip_do_quantsmooth_band: this rank's band of a job whose halo rows travel through RCCL (`comm`: ncclComm_t as int)"""
+        job, work = self._make_job(coefs, quants, kw.get("hsamp"), kw.get("vsamp"), kw.get("colorspace"), kw.get("image_size"))
+        ret = self._check(self.lib.qs_hip_do_quantsmooth_band(C.byref(job), flags, niter, rank, nranks, comm))
+        return self._job_result(job, work, quants, ret)
 
     def set_shard_schedule(self, schedule: int):
         """qs_hip_set_shard_schedule: 0 = one halo row per iteration, 1 = deep halo (no exchange), -1 = default"""

@@ -331,6 +331,9 @@ def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
         assert pr.get("error") is None, pr
         assert pr["entry"] == "qs_hip_do_quantsmooth_sharded" and pr["devices"] == [0, 0]
         assert pr["equals_one_device_result"] is True and pr["verify_ok"] is True
+        # ... and the communication-avoiding schedule: same rows as the exchange schedule, without any exchange
+        dh = d["deep_halo_schedule"]
+        assert dh["equals_exchange_schedule"] is True and dh["value_batch1"] > 0 and dh["rows_owned_and_held"] == [64, 67]
 
 
 @pytest.mark.gpu

@@ -124,3 +124,88 @@ def test_multigpu_first_contact_script_runs_on_this_box(gpu, tmp_path):
     text = (ROOT / "tools" / "first_contact.sh").read_text()
     for piece in ("first_contact_p2p", "first_contact_shard.py", "bench.py --gpus", "tests/test_multigpu.py", "SUMMARY.txt"):
         assert piece in text
+
+
+# ---- qs_hip_do_quantsmooth_band: one band per process / thread, halo rows through RCCL behind the C ABI ----------------------
+
+def _rccl():
+    import ctypes as C
+    try:
+        lib = C.CDLL("librccl.so.1", mode=os.RTLD_GLOBAL)
+    except OSError:
+        pytest.skip("librccl.so.1 is not loadable on this box")
+    lib.ncclCommInitAll.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
+    lib.ncclCommDestroy.argtypes = [C.c_void_p]
+    return lib
+
+
+def _band_job_and_truth(synth, oracle, flags, niter):
+    j = synth.synth_ycc(264, 1040, 1, 1, quality=45, seed=17)   # 130 x 33 blocks per component, 4:4:4: every component cut alike
+    kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(264, 1040))
+    return j, kw, oracle.do_quantsmooth(j["coefs"], j["quants"], flags, niter, threads=8, **kw)
+
+
+def test_multigpu_rccl_band_entry_degenerate_one_rank(gpu, synth, oracle):
+    """qs_hip_do_quantsmooth_band with nranks = 1: the whole image is the band, no neighbour -- once without a
+    communicator, once with a real one-rank RCCL communicator (librccl looked up in the caller's copy, the range-check
+    flags all-reduced through it).  Bit-exact; the coupled flags are refused; a tripped range check writes nothing."""
+    import ctypes as C
+    from helpers import assert_same_result, load_golden
+    rccl = _rccl()
+    comm = C.c_void_p()
+    dev = (C.c_int * 1)(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, dev) == 0
+    try:
+        for flags, niter in ((0, 3), (1, 2), (32, 2)):
+            j, kw, want = _band_job_and_truth(synth, oracle, flags, niter)
+            for c in (None, comm):
+                got = gpu.do_quantsmooth_band(j["coefs"], j["quants"], flags, niter, 0, 1, c, **kw)
+                assert_same_result(got, want, f"band entry, one rank, flags {flags}, comm {c is not None}")
+        with pytest.raises(Exception) as e:
+            gpu.do_quantsmooth_band(j["coefs"], j["quants"], 7, 2, 0, 1, comm, **kw)
+        assert getattr(e.value, "code", None) == -4                     # QS_HIP_ENOTSUP
+        job, _ = load_golden("gray64_badcoef_q3_n2")
+        got = gpu.do_quantsmooth_band(job["coefs"], job["quants"], job["flags"], job["niter"], 0, 1, comm, **job["kw"])
+        assert got["ret"] == 2                                            # QS_HIP_BAND_RANGE_CHECK
+        assert all((a == b).all() for a, b in zip(got["coefs"], job["coefs"]))   # nothing written
+    finally:
+        rccl.ncclCommDestroy(comm)
+
+
+def test_multigpu_rccl_band_entry_real_devices(gpu, synth, oracle):
+    """N threads, one per device, each with its band of the image and its rank of one RCCL clique (ncclCommInitAll):
+    ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd between the iterations -- the bands put together equal the
+    unsharded result"""
+    import ctypes as C
+    import threading
+    import numpy as np
+    import torch
+    if _ndev(gpu) < 2:
+        pytest.skip(f"needs >= 2 HIP devices, {_ndev(gpu)} visible")
+    rccl = _rccl()
+    n = _counts(gpu)[-1]
+    comms = (C.c_void_p * n)()
+    devs = (C.c_int * n)(*range(n))
+    assert rccl.ncclCommInitAll(comms, n, devs) == 0
+    try:
+        for flags, niter in ((0, 3), (1, 2)):
+            j, kw, want = _band_job_and_truth(synth, oracle, flags, niter)
+            hb = j["coefs"][0].shape[0]
+            parts, errs = [None] * n, []
+
+            def work(r):
+                try:
+                    torch.cuda.set_device(r)
+                    r0, r1 = gpu.band_rows(hb, n, r)
+                    parts[r] = gpu.do_quantsmooth_band([c[r0:r1] for c in j["coefs"]], j["quants"], flags, niter, r, n, comms[r], **kw)
+                except Exception as ex:  # noqa: BLE001
+                    errs.append((r, ex))
+            th = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+            [t.start() for t in th]; [t.join() for t in th]
+            assert not errs, errs
+            for ci in range(3):
+                got = np.concatenate([p["coefs"][ci] for p in parts], axis=0)
+                assert np.array_equal(got, want["coefs"][ci]), (flags, ci)
+    finally:
+        for c in comms:
+            rccl.ncclCommDestroy(c)

@@ -31,6 +31,20 @@ def test_sharded_gray_equals_unsharded(gpu, oracle, synth, nbands):
         assert_same_result(got, want, f"gray {nbands} bands flags={flags}")
 
 
+def test_band_entry_argument_checks(hip):
+    """no GPU needed: qs_hip_do_quantsmooth_band validates rank / communicator; librccl is NOT a link-time dependency"""
+    import ctypes as C
+    import subprocess
+    from jpeg_quantsmooth_amd.hipqs import lib_path
+    job, _ = hip._make_job([np.zeros((8, 2, 64), np.int16)], [np.full(64, 4, np.uint16)])
+    f = hip.lib.qs_hip_do_quantsmooth_band
+    assert f(C.byref(job), 0, 3, 2, 2, None) == -2               # rank out of range
+    assert f(C.byref(job), 0, 3, 0, 2, None) == -2               # two ranks need a communicator
+    assert f(C.byref(job), 0, 0, 0, 1, None) == 0                # niter 0: the reference's early-out, before any device
+    needed = subprocess.run(["readelf", "-d", str(lib_path())], capture_output=True, text=True).stdout
+    assert "librccl" not in needed and "libamdhip64" in needed
+
+
 def test_shard_schedule_setter(hip):
     """no GPU needed: qs_hip_set_shard_schedule validates its argument"""
     assert hip.lib.qs_hip_set_shard_schedule(2) == -2 and hip.lib.qs_hip_set_shard_schedule(-2) == -2
