@@ -80,6 +80,22 @@ ALGO_BYTES_PER_BLOCK_ITER = 256
 RESIDENT_BUDGET = 64 << 30     # HBM the resident input planes of all steps may take
 
 
+KERNEL_SOURCES = ("qs_kernels.hip", "qs_smooth_kernel.inc", "qs_smooth_dp_kernel.inc", "qs_devfn.h", "qs_device.h", "qs_launch.h",
+                  "strip_asm_nops.py", "build_stripped.sh")
+
+
+def kernel_sources_sha1():
+    """what the device code of the recovery kernels is built from (jpeg-quantsmooth_amd/csrc): profiles/pmc_traffic.json
+    records this hash next to the PMC counters it holds, so a `roofline.traffic` measured on OTHER kernel sources shows in
+    the bench line (`traffic_kernel_hash.match` false) instead of passing as current"""
+    import hashlib
+    h = hashlib.sha1()
+    for name in KERNEL_SOURCES:
+        f = ROOT / "jpeg-quantsmooth_amd" / "csrc" / name
+        h.update(name.encode() + b"\0" + (f.read_bytes() if f.exists() else b"<missing>") + b"\0")
+    return h.hexdigest()[:16]
+
+
 def _sustained(achieved_tf):
     """the same fraction against what the chip SUSTAINS for a pure stream of this kernel's term instructions
     (profiles/valu_sustained.json, measured with tools/ubench_clock.hip): the shader clock under a full VALU load
@@ -121,7 +137,11 @@ def parse_args():
     ap.add_argument("--verify", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="torch.distributed backend (gloo: functional test of the sharded path)")
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (functional test of the sharded path on a 1-GPU box, with --backend gloo)")
+    ap.add_argument("--print-kernel-hash", action="store_true", help="print kernel_sources_sha1() (what profiles/pmc_traffic.json is tied to) and exit")
     a = ap.parse_args()
+    if a.print_kernel_hash:
+        print(kernel_sources_sha1())
+        sys.exit(0)
     if a.niter is None:
         a.niter = 5 if a.quality >= 5 else 3
     return a
@@ -385,11 +405,13 @@ def main():
         # `traffic` is NOT measured by this run: it is the PMC figure (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the
         # gfx950 corrections of MI355X_MICROARCH.md) of an earlier profiled run of the same command, kept in
         # profiles/pmc_traffic.json; `traffic_measured_in` names the profile folder it came from, so a stale figure is visible.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_hash = None, None, None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists() and not colour and world == 1:
             try:
                 j = json.loads(pmc.read_text())
+                tree = kernel_sources_sha1()
+                traffic_hash = {"measured_on": j.get("kernel_sources_sha1"), "this_tree": tree, "match": j.get("kernel_sources_sha1") == tree}
                 ppl = res.get("planes_per_launch", 1)
                 det = j.get(f"set{ppl}_detail", {}).get(f"q{args.quality}", {}) if ppl > 1 else {}
                 traffic = j.get(f"q{args.quality}_{size}_set{ppl}") if ppl > 1 else None
@@ -431,7 +453,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": res["kernel"], "achieved": achieved_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_measured_in": traffic_src,
-                         "traffic_kind": "PMC counters of an earlier profiled run of this command (profiles/pmc_traffic.json); not re-measured by this run",
+                         "traffic_kind": "PMC counters of an earlier profiled run of this command (profiles/pmc_traffic.json); not re-measured by this run"
+                                         + ("" if (traffic_hash or {}).get("match") else " -- STALE: taken on other kernel sources than this tree's (traffic_kernel_hash)"),
+                         "traffic_kernel_hash": traffic_hash,
                          "kernel_ms": kern_ms,
                          "kernel_launches_timed": res["kernel_launches"],
                          "algorithmic_bytes_per_launch": kblocks * ALGO_BYTES_PER_BLOCK_ITER,

@@ -19,8 +19,10 @@ TMP=$(mktemp -d "${TMPDIR:-/tmp}/qs_strip.XXXXXX") || exit 1
 trap 'rm -rf "$TMP"' EXIT
 B=$TMP/k
 
+# plain <why> <hipcc flags ...>
 plain() {
-  echo "build_stripped.sh: WARNING: $1 -- building $OUT with the plain one-step hipcc -c (no-ops between asm statements stay: 2-6 % slower kernels)" >&2
+  local why=$1; shift                # (the remaining arguments are the hipcc flags; the message must not reach hipcc)
+  echo "build_stripped.sh: WARNING: $why -- building $OUT with the plain one-step hipcc -c (no-ops between asm statements stay: 2-6 % slower kernels)" >&2
   [ "${QS_REQUIRE_STRIP:-0}" = 1 ] && { echo "build_stripped.sh: QS_REQUIRE_STRIP=1: giving up" >&2; exit 1; }
   exec "$HIPCC" "$@" -c "$SRC" -o "$OUT"
 }

@@ -38,6 +38,11 @@ struct FGroup {
   // worth in the reference's progress units (own block rows x v_samp; halo rows of a band are somebody else's work)
   std::vector<hipEvent_t> it_ev;
   long long units = 0;
+  // ... and the range-check flags right behind pass A of iteration 0 (the only pass that sets them): the reference makes
+  // no progress call for a component whose range check trips (quantsmooth.h:2610 leaves the loop first), so the calls of
+  // this group wait until ITS flags are known to be clear
+  PinnedBuf hstatus0;
+  hipEvent_t ev_status0 = nullptr;
   // QS_HIP_TRACE only: device timestamps "input is on the device" / "kernels done" / "results are in pinned host memory"
   hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
   float t_ms[3] = {0, 0, 0};              // ... in ms after the call's first event, read when the group is drained
@@ -47,11 +52,12 @@ struct FGroup {
   ~FGroup() {
     for (hipEvent_t& e : tev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (hipEvent_t& e : it_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (ev_status0) { (void)hipEventDestroy(ev_status0); ev_status0 = nullptr; }
   }
   // everything queued on the group's stream has completed: give the arenas back
   void release_transients(bool keep_stage) {
     coef.release(); px.release(); cst.release(); status.release();
-    hstatus.release(); down.reset();
+    hstatus.release(); hstatus0.release(); down.reset();
     if (!keep_stage) stage.release();
   }
 };
@@ -219,6 +225,12 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
     // pass A once (dequantise, range check, first pixel planes); every pass B but the last writes the next
     // iteration's planes itself (fused pass A, ping-pong between the two planes of each FPlane)
     qs_launch_idct_set(set, 1, G.s);
+    if (plan) {                                              // the flags as pass A left them, for the progress calls (see FGroup)
+      if (!G.hstatus0.alloc((size_t)np * sizeof(int32_t))) return qs_fail(QS_HIP_ENOMEM, "out of pinned host memory");
+      HIP_TRY(hipMemcpyAsync(G.hstatus0.p, G.status.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, G.s));
+      HIP_TRY(hipEventCreateWithFlags(&G.ev_status0, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(G.ev_status0, G.s));
+    }
     for (int it = 0; it < niter; ++it) {
       for (int i = 0; i < np; ++i) {
         uint8_t* a = G.px.as<uint8_t>() + G.planes[i].px_off;
@@ -264,7 +276,13 @@ int qsj::run_fused(qs_hip_job* const* jobs, const std::vector<int>& which, int f
     // calls whose share of the work is done are made now, in the reference's sequence.  A cancel is handled like a
     // tripped range check: nothing more of the job is written, rows already written are restored, and the job is
     // re-run in the reference's order with the recorded answers (below).
-    if (plan && !plan->cancelled)
+    bool tripped = false;
+    if (plan && G.ev_status0) {                              // the group's range check first: a tripped group reports nothing
+      HIP_TRY(hipEventSynchronize(G.ev_status0));
+      const int32_t* h0 = static_cast<const int32_t*>(G.hstatus0.p);
+      for (size_t i = 0; i < G.planes.size(); ++i) if (h0[i]) { bad_job[G.planes[i].job] = 1; tripped = true; }
+    }
+    if (plan && !plan->cancelled && !tripped)
       for (hipEvent_t e : G.it_ev) {
         HIP_TRY(hipEventSynchronize(e));
         units_done += G.units;

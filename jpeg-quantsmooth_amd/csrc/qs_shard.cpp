@@ -66,7 +66,8 @@ struct Band {            // one (logical) device
   hipEvent_t evT0 = nullptr, evT1 = nullptr;   // QS_HIP_TRACE only: first pass A .. last pass B on this band's stream
   std::vector<BandPlane> planes;
   DevBuf coef, px, cst, status, aux[8];   // aux: route-specific planes (colour route)
-  PinnedBuf stage, hstatus;
+  PinnedBuf stage, hstatus, hstatus0;      // hstatus0 / evS: the range-check flags right behind pass A of iteration 0 (progress route)
+  hipEvent_t evS = nullptr;
   Download down, down_up[2];
   std::vector<QsConsts> hc;
   QsPlaneSet set;
@@ -91,6 +92,7 @@ struct Bands {
       for (hipEvent_t e : B.evX) if (e) (void)hipEventDestroy(e);
       if (B.evT0) (void)hipEventDestroy(B.evT0);
       if (B.evT1) (void)hipEventDestroy(B.evT1);
+      if (B.evS) (void)hipEventDestroy(B.evS);
       B.down.reset(); B.down_up[0].reset(); B.down_up[1].reset();
       B.coef.release(); B.px.release(); B.cst.release(); B.status.release();
       for (auto& a : B.aux) a.release();
@@ -365,6 +367,15 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
         HIP_TRY(hipSetDevice(B.dev));
         if (int r = before_overwrite(bands, d)) return r;
         qs_launch_idct_set(B.set, 1, B.s);
+        if (plan) {
+          // the range check is pass A's: its flags travel now, so that no progress call is made for a job the reference
+          // would have left before its first call (quantsmooth.h:2610)
+          const size_t np = std::max<size_t>(1, B.planes.size());
+          if (!B.hstatus0.alloc(np * sizeof(int32_t))) return qs_fail(QS_HIP_ENOMEM, "out of pinned host memory");
+          HIP_TRY(hipMemcpyAsync(B.hstatus0.p, B.status.p, np * sizeof(int32_t), hipMemcpyDeviceToHost, B.s));
+          HIP_TRY(hipEventCreateWithFlags(&B.evS, hipEventDisableTiming));
+          HIP_TRY(hipEventRecord(B.evS, B.s));
+        }
       }
     // one pixel row per component and band edge, of the planes this iteration's pass B reads
     if (!deep)
@@ -415,12 +426,24 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
     long long per_iter = 0;
     for (int ci = 0; ci < job->ncomp; ++ci) per_iter += (long long)job->hblk[ci] * job->vsamp[ci];
     const size_t nb = bands.b.size();
+    for (Band& B : bands.b) {                                // every band's range check before the first call
+      HIP_TRY(hipSetDevice(B.dev));
+      HIP_TRY(hipEventSynchronize(B.evS));
+      const int32_t* h0 = static_cast<const int32_t*>(B.hstatus0.p);
+      for (size_t i = 0; i < B.planes.size(); ++i)
+        if (h0[i]) {
+          for (Band& C : bands.b) { HIP_TRY(hipSetDevice(C.dev)); HIP_TRY(hipStreamSynchronize(C.s)); }
+          return JOB_RERUN_CAREFUL;                          // host input untouched, no call made: the careful route makes them live
+        }
+    }
     for (int it = 0; it < niter && !plan->cancelled; ++it) {
       for (size_t d = 0; d < nb; ++d) {
         const ItEv& x = it_ev[(size_t)it * nb + d];
         HIP_TRY(hipSetDevice(x.dev));
         HIP_TRY(hipEventSynchronize(x.e));
       }
+      // the callback runs on the caller's device, whatever band was synchronised last (it may use HIP / torch itself)
+      HIP_TRY(hipSetDevice(bands.home));
       plan->advance(per_iter * (it + 1));
     }
     if (plan->cancelled) {

@@ -218,6 +218,21 @@ for progprec in (0, -1, 7):
             logs.append((calls, res))
         assert logs[0][0] == logs[1][0], (mode, progprec, cancel_at, logs[0][0], logs[1][0])
         assert_same_result(logs[0][1], logs[1][1], "%%s progprec=%%d cancel_at=%%s" %% (mode, progprec, cancel_at))
+# a coefficient that fails the range check (reference quantsmooth.h:2599-2610): the reference leaves the component before
+# its first progress call -- the pipelined routes read the flags right behind pass A and make no call of their own
+for ci in range(len(coefs)):
+    bad = [c.copy() for c in coefs]
+    bad[ci][1, 2, 0] = 0x7ff
+    logs = []
+    for impl in (gpu, oracle):
+        calls = []
+        def cb(_u, cur, mx, calls=calls):
+            calls.append((cur, mx)); return 0
+        res = impl.do_quantsmooth(bad, quants, 1, niter, progprec=-1, progress=cb, **kw)
+        logs.append((calls, res))
+    assert logs[0][0] == logs[1][0], (mode, "bad coefficient in component", ci, logs[0][0][:6], logs[1][0][:6])
+    assert logs[1][1]["ret"] == 1 and (ci > 0 or not logs[1][0])
+    assert_same_result(logs[0][1], logs[1][1], "%%s bad coefficient in component %%d" %% (mode, ci))
 print("PROGRESS_OK")
 """
 
