@@ -6,7 +6,7 @@ plane, inputs resident in HBM.  A "step" is one pass of the hot path over one BA
 synthetic input: `--batch` (default 12) independent 8192x8192 planes, each taken through
 a complete do_quantsmooth -- the IDCT-to-plane kernel once, then niter x {[halo exchange],
 recovery kernel}: every recovery launch but the last also writes the next iteration's pixel
-planes (pass A fused into pass B); final clamp fused into the last launch.  The planes of a step travel
+planes (pass A fused into pass B, LABNOTES.md 4.2f); final clamp fused into the last launch.  The planes of a step travel
 together as one plane set: one launch per pass covers all of them (the job layer's
 qs_hip_idct_planes / qs_hip_smooth_planes), at every N.  (20 driver steps of 12 planes cover
 about a second, i.e. the power-capped steady state; `value` counts blocks.)
@@ -53,7 +53,7 @@ Extra legs of the luma workload (not part of `value`; `--no-extras` skips them):
   deep_halo_schedule               N > 1: the single image on the communication-avoiding schedule, timed like value_batch1; its owned
                                    rows must equal the exchange schedule's
   smooth_input                     N = 1: the same workload on the smooth variant of the image (periods x10, no noise),
-                                   where the wave-uniform need_refresh skip applies
+                                   where the wave-uniform need_refresh skip applies (LABNOTES.md 4.2c)
   product_route                    the PRODUCT's own multi-GPU route over the same N devices -- qs_hip_do_quantsmooth_sharded
                                    (csrc/qs_shard.cpp: one process, peer copies), host arrays in and out, run as a child
                                    process of rank 0 while the other ranks wait on a host-side (gloo) barrier
@@ -122,7 +122,7 @@ def parse_args():
     ap.add_argument("--weak", action="store_true", help="give every rank a full size x size plane")
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1: interior rows on the main stream while halo exchange + edge rows run on a side stream "
-                         "(measured slower on MI355X than the default in-order schedule, see DESIGN.md section 8)")
+                         "(measured slower on MI355X than the default in-order schedule, see LABNOTES.md section 8)")
     ap.add_argument("--no-overlap", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sweep")

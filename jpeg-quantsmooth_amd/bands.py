@@ -256,7 +256,7 @@ def run_bands_batched_sets(hip, engines, topo: BandTopology, niter: int, exchang
     """run_bands_batched with ONE launch per pass for all planes of the batch (plane sets,
     qs_hip_idct_planes / qs_hip_smooth_planes): a 1/8 band of an 8192^2 plane is 2048 waves, two per
     SIMD -- launched alone it runs at 72 % of the rate the same kernel reaches once the chip is full
-    (DESIGN.md 4.2b table); twelve bands in one launch fill it.  HipBandEngine objects only.
+    (LABNOTES.md 4.2b table); twelve bands in one launch fill it.  HipBandEngine objects only.
 
     fused (default): pass A runs ONCE; every pass B but the last writes the next iteration's pixel planes itself
     (the parallel d_plane_next[] array of qs_hip_smooth_planes_next) into each engine's second plane, and the engines' `plane` / `plane2` swap --

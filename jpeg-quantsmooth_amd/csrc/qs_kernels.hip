@@ -22,8 +22,8 @@
 // for the coalesced-load transpose).  147 VGPRs => 3 waves per SIMD.
 //
 // This translation unit holds the SHIPPED kernels only.  The variants that were built and
-// measured on the way (and lost) are kept, compilable, under csrc/experiments/ and are
-// built only by tools/build_variants.sh; DESIGN.md has the numbers.
+// measured on the way (and lost) are kept, compilable, under tools/experiments/ and are
+// built only by tools/build_variants.sh; LABNOTES.md has the numbers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -346,7 +346,7 @@ typedef int qs_i4 __attribute__((ext_vector_type(4)));         // one per-coeffi
 // LDS slice), so the size only sets the dispatch granularity
 #define QS_WAVES_PER_WG 4
 // register budget: 3 waves per SIMD (168 VGPRs; the kernel uses 147).  Measured: 2 waves per SIMD -11 %, a
-// 4-wave budget (128 VGPRs, edge differences recomputed per term) -7.5 %.
+// 4-wave budget (128 VGPRs, edge differences recomputed per term) -7.5 % (LABNOTES.md 4.2).
 #define QS_SMOOTH_MIN_WAVES 3
 // workgroups the chip holds at once = 256 CUs x 3 (a workgroup puts one wave on each of a CU's four SIMDs):
 // the tail-round rule of qs_smooth_kernel.inc

@@ -63,7 +63,7 @@ def test_plane_ref_keeps_its_original_size_and_abi_version():
 
 
 def test_experiments_translation_unit_still_builds(tmp_path):
-    """csrc/experiments/ (round-3 kernel variants, built only by tools/build_variants.sh) must keep compiling against the
+    """tools/experiments/ (round-3 kernel variants, built only by tools/build_variants.sh) must keep compiling against the
     product's headers and keep defining every launcher csrc/qs_launch.h declares for qs_kernels.hip -- otherwise a variant
     library links with holes and fails only on the GPU box"""
     import shutil
@@ -74,7 +74,7 @@ def test_experiments_translation_unit_still_builds(tmp_path):
     csrc = ROOT / "jpeg-quantsmooth_amd" / "csrc"
     obj = tmp_path / "exp.o"
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
-                    "-Wno-unused-function", f"-I{csrc}", "-c", str(csrc / "experiments" / "qs_kernels_r03.hip"), "-o", str(obj)],
+                    "-Wno-unused-function", f"-I{csrc}", "-c", str(ROOT / "tools" / "experiments" / "qs_kernels_r03.hip"), "-o", str(obj)],
                    check=True, capture_output=True, timeout=900)
     have = subprocess.run(["nm", "-C", "--defined-only", str(obj)], capture_output=True, text=True, check=True).stdout
     ship = subprocess.run(["nm", "-C", "--defined-only", str(csrc / "qs_kernels.o")], capture_output=True, text=True, check=True).stdout

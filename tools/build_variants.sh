@@ -2,7 +2,7 @@
 # Build tuning variants of libjpegqs_hip.so into build/variants/ (measurement only).
 #   tools/build_variants.sh "name1:-DFLAG=1 -DX=2" "name2:..."
 # A spec "name:..." is built from the SHIPPED kernel source (csrc/qs_kernels.hip) when its flags start with "@ship",
-# otherwise from the round-3 experiments source with all of its QS_* switches (csrc/experiments/qs_kernels_r03.hip).
+# otherwise from the round-3 experiments source with all of its QS_* switches (tools/experiments/qs_kernels_r03.hip).
 set -e
 cd "$(dirname "$0")/../jpeg-quantsmooth_amd/csrc"
 OUT=../../build/variants; rm -rf $OUT; mkdir -p $OUT
@@ -11,7 +11,7 @@ for f in qs_tables qs_planes qs_job qs_fused qs_batch qs_shard; do hipcc $HIPFLA
 hipcc $HIPFLAGS -c qs_kernels_aux.hip -o $OUT/qs_aux.o
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
-  src=experiments/qs_kernels_r03.hip
+  src=../../tools/experiments/qs_kernels_r03.hip
   case "$flags" in "@ship"*) src=qs_kernels.hip; flags=${flags#@ship} ;; esac
   if [ $src = qs_kernels.hip ]; then   # the shipped source gets the shipped build steps (csrc/build_stripped.sh: no-ops between asm statements stripped)
     bash build_stripped.sh $src $OUT/k_$name.o 0 $HIPFLAGS -I. $flags

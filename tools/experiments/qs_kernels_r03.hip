@@ -22,13 +22,13 @@
 // for the coalesced-load transpose).  128 VGPRs => 4 waves per SIMD.
 //
 // Build-time switches (all default to the measured-best setting; the others are
-// kept as checked-in experiments): QS_SMOOTH_MIN_WAVES,
+// kept as checked-in experiments, see LABNOTES.md): QS_SMOOTH_MIN_WAVES,
 // QS_PIN_DIFFS, QS_PIN_EDGE, QS_SKIP_ZERO_WEIGHTS, QS_SMEM_PIPELINE,
 // QS_IDCT_DOT2, QS_ABLATE_*.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include "../qs_device.h"
+#include "qs_device.h"
 
 /* QS_LDS_PITCH: qs_device.h */
 
@@ -318,7 +318,7 @@ qs_idct_plane_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coe
   idct_block_to_plane(cst, coef, plane, wblk, hblk, pitch, first, rep_top, rep_bot, status, blk);
 }
 
-#include "../qs_devfn.h"
+#include "qs_devfn.h"
 
 // pass A over a set of planes (whole planes, or bands whose halo-side apron rows are left alone)
 __global__ void __launch_bounds__(256)
@@ -559,7 +559,7 @@ extern "C" int qs_hip_debug_timeline(void* dev_buf) {
 #endif
 #define QS_RESIDENT_WG (256 * QS_SMOOTH_OCCUPANCY * 4 / QS_WAVES_PER_WG)
 // measurement only: extra (unused) LDS dwords per wave, to cap how many workgroups a CU holds
-// without touching the code (occupancy experiments: 2400 -> 2 waves per SIMD), see DESIGN.md
+// without touching the code (occupancy experiments: 2400 -> 2 waves per SIMD), see LABNOTES.md
 #ifndef QS_LDS_EXTRA
 #define QS_LDS_EXTRA 0
 #endif
@@ -693,7 +693,7 @@ qs_dequant_kernel(const QsConsts* __restrict__ cst, int16_t* __restrict__ coef, 
 
 // --------------------------------------------------------------------------
 // launchers (C++ linkage, used by qs_planes.cpp and qs_job.cpp through qs_launch.h)
-#include "../qs_launch.h"
+#include "qs_launch.h"
 
 void qs_launch_idct_plane(const QsConsts* cst, int16_t* coef, uint8_t* plane, int wblk, int hblk,
                           int first, int rep_top, int rep_bot, int* status, hipStream_t s) {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes tools/ubench_lut.hip: issue-rate probes for a table-driven form of the recovery term
-(QS_LUT).  In  t = max(R-|d|,0)^2; x = d*t; y = w*t; num += x*y; den += y*y  the pair
+(LABNOTES.md 4.2, QS_LUT).  In  t = max(R-|d|,0)^2; x = d*t; y = w*t; num += x*y; den += y*y  the pair
 (t, x) depends only on the integer pixel difference d and the coefficient's range R, so it can come
 from a 511-entry table in LDS: one v_sub_u32_sdwa (address) + one ds_read_b64 replace three VALU
 operations.  Whether that pays depends on what limits the kernel: the two VALU pipes of a SIMD (then

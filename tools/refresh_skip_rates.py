@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How often could the refresh IDCT at an anti-diagonal start be skipped (reference quantsmooth.h:1407-1409:
 "if need_refresh") -- per block, and per WAVE of 64 consecutive blocks (what the GPU kernel can exploit,
-DESIGN.md 4.2c)?  CPU only: builds an instrumented copy of the test oracle under /tmp (a per-block bit mask of
+LABNOTES.md 4.2c)?  CPU only: builds an instrumented copy of the test oracle under /tmp (a per-block bit mask of
 the anti-diagonals whose refresh was needed) and runs one iteration on several inputs.
     python tools/refresh_skip_rates.py > profiles/r03_info/refresh_skip_rates.txt"""
 import ctypes as C
