@@ -147,3 +147,20 @@ def test_multithreaded_oracle_is_deterministic(oracle, synth):
     a = oracle.do_quantsmooth([coef], [quant], 1, 2, threads=1)
     b = oracle.do_quantsmooth([coef], [quant], 1, 2, threads=4)
     assert_same_result(a, b)
+
+
+def test_fuzz_corpus_is_what_the_compiled_reference_produces(reference, tmp_path):
+    """tests/golden/fuzz_s2.jsonl (400 trials / 959 jobs, every flags value, all layouts; replayed by the GPU suite in
+    every kernel form and route) holds hashes of expected outputs.  Regenerated here from the COMPILED, UNMODIFIED
+    reference (tools/fuzz_gpu.py gen with FUZZ_TRUTH=ref): the file must come out byte for byte -- the GPU suite's fuzz
+    replays are then comparisons with oracle/_ref itself, not with the port."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    out = tmp_path / "fuzz_ref.jsonl"
+    r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_gpu.py"), "gen", str(out), "400", "2"],
+                       capture_output=True, text=True, timeout=1500, cwd=str(root), env=dict(os.environ, FUZZ_TRUTH="ref"))
+    assert r.returncode == 0 and "truth = Reference" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+    assert out.read_bytes() == (root / "tests" / "golden" / "fuzz_s2.jsonl").read_bytes()

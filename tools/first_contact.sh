@@ -4,11 +4,13 @@
 #   (a) tools/first_contact_p2p      peer-access matrix, hipMemcpyPeerAsync ring with the cross-device event protocol of
 #                                    csrc/qs_shard.cpp, every byte checked; halo latency per round, xGMI GB/s per hop
 #   (b) tools/first_contact_shard.py qs_hip_do_quantsmooth_sharded over devices 0..N-1: 8192^2 q3, 16384^2 q3,
-#                                    8192^2 4:2:0 q6 n5 -- EVERY block against the compiled reference (libqsref_none.so)
+#                                    8192^2 4:2:0 q6 n5 -- EVERY block against the compiled reference (libqsref_none.so);
+#                                    then again with QS_HIP_SHARD_SCHEDULE=deep (no halo exchange): the schedules' A/B
 #   (c) bench.py --gpus 2/4/8        RCCL band driver: q3 with 12 planes per step (`value`) and with one (`--batch 1`:
 #                                    single-image strong scaling), q6; `--backend nccl` (the default) ENDS the run if RCCL
 #                                    does not come up -- a host-staged number never looks like a result
-#   (d) pytest -m gpu -k multigpu    the same three steps as tests (tests/test_multigpu.py; they skip below 2 devices)
+#   (d) pytest -m gpu -k multigpu    the same three steps as tests, plus qs_hip_do_quantsmooth_band (one thread per device,
+#                                    halo rows through RCCL behind the C ABI) -- tests/test_multigpu.py; they skip below 2 devices
 # Everything lands in ONE folder, gpurun_out/first_contact/ (or $1), with a PASS / FAIL line per step in SUMMARY.txt.
 #   bash tools/first_contact.sh [outdir] [N ...]         N defaults to every power of two up to the visible device count
 # On a one-GPU box every step runs in its degenerate form (N = 1).
@@ -41,6 +43,9 @@ for n in $NS; do step "a_p2p_n$n" 120 tools/first_contact_p2p "$n" 64 || FAILS=$
 for n in $NS; do
   devs=$(seq -s, 0 $((n - 1)))
   step "b_shard_n$n" 1500 python tools/first_contact_shard.py --devices "$devs" || FAILS=$((FAILS + 1))
+  # the same three configurations on the COMMUNICATION-AVOIDING schedule (niter extra block rows per cut side, no halo
+  # exchange; qs_hip_set_shard_schedule(1)): the A/B of the two schedules on real links is the `ms` column of the two logs
+  [ "$n" -ge 2 ] && { step "b_shard_deep_n$n" 1500 env QS_HIP_SHARD_SCHEDULE=deep python tools/first_contact_shard.py --devices "$devs" || FAILS=$((FAILS + 1)); }
 done
 
 # (c) the RCCL band driver: q3 (12 planes per step, then one), q6
@@ -59,7 +64,8 @@ else:
     d = json.loads(lines[-1])
     print(f"      value {d['value'] / 1e6:.1f} M blocks/s, ms/step {d['ms_per_step']:.2f}, n_gpus {d['n_gpus']}, rccl_ranks {d['config'].get('rccl_ranks')}, "
           f"verify_ok {d.get('verify_ok')}, band edges {d.get('verify_band_edges_ok')}, value_batch1 {d.get('value_batch1')}, "
-          f"product_route {(d.get('product_route') or {}).get('ms_per_image')}")
+          f"product_route {(d.get('product_route') or {}).get('ms_per_image')}, "
+          f"deep-halo schedule batch1 {(d.get('deep_halo_schedule') or {}).get('value_batch1')} (equal: {(d.get('deep_halo_schedule') or {}).get('equals_exchange_schedule')})")
 PY
   done
 done

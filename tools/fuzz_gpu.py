@@ -74,8 +74,13 @@ def kwargs(j):
 
 
 if mode == "gen":
-    from oracle.oracle import Oracle          # the replay side (`run`) never touches the oracle
-    oracle = Oracle()
+    from oracle.oracle import Oracle, Reference, have_ref   # the replay side (`run`) never touches the oracle
+    # FUZZ_TRUTH=ref: the expected hashes come from the COMPILED, UNMODIFIED reference (oracle/_ref/libqsref_none.so) instead
+    # of the plain-C port -- slower, and how the committed corpus was re-derived in round 6 (identical file: the port is
+    # pinned to the reference on CPU, this shows it on the corpus itself)
+    import os
+    oracle = Reference("none") if os.environ.get("FUZZ_TRUTH") == "ref" and have_ref("none") else Oracle()
+    print("gen: truth =", type(oracle).__name__)
     ntrials = int(sys.argv[3]); seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     t0 = time.time()
     with open(path, "w") as f:
