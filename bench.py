@@ -52,6 +52,8 @@ Extra legs of the luma workload (not part of `value`; `--no-extras` skips them):
                                    schedule (niter extra block rows per cut side, no exchange)
   deep_halo_schedule               N > 1: the single image on the communication-avoiding schedule, timed like value_batch1; its owned
                                    rows must equal the exchange schedule's
+  edge_first_schedule              N > 1: the single image on the latency-hiding schedule (edge rows + exchange on a side stream while the
+                                   interior rows run), timed like value_batch1; same result required
   smooth_input                     N = 1: the same workload on the smooth variant of the image (periods x10, no noise),
                                    where the wave-uniform need_refresh skip applies (LABNOTES.md 4.2c)
   product_route                    the PRODUCT's own multi-GPU route over the same N devices -- qs_hip_do_quantsmooth_sharded
@@ -467,7 +469,7 @@ def main():
                               "flop_per_block_iter": FLOP_PER_BLOCK_ITER[flags & 1],
                               **_sustained(achieved_tf)},
         }
-        for k in ("single_plane_ms", "value_batch1", "planes_identical", "smooth_input", "scaling_emulation", "deep_halo_schedule", "product_route", "verify_against"):
+        for k in ("single_plane_ms", "value_batch1", "planes_identical", "smooth_input", "scaling_emulation", "deep_halo_schedule", "edge_first_schedule", "product_route", "verify_against"):
             if res.get(k) is not None:
                 out[k] = res[k]
         for k in ("verify_ok", "verify_rows", "verify_detail", "verify_band_edges_ok"):
@@ -562,6 +564,29 @@ def _scaling_emulation(torch, hip, bands, full, quant, flags, niter, dev, hblk_t
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
         return ms, float(np.mean([a.elapsed_time(b) for a, b in pairs])) * 1e3
+    side = torch.cuda.Stream(device=dev)
+
+    def time_edge_first(src, topo, wait_us):
+        """the latency-hiding schedule (bands.run_band_edge_first): edge block rows + exchange on a side stream, interior
+        rows on the main stream; the exchange is two device copies + the injected wait, on the side stream"""
+        work = [src.clone() for _ in range(steps + 2)]
+        eng = bands.HipBandEngine(hip, torch, work[0], quant, flags, luma=1, device=dev)
+        h = eng.hblk * 8
+
+        def fake_exchange():
+            eng.row(-1).copy_(eng.row(0)); eng.row(h).copy_(eng.row(h - 1))
+            if wait_us and delay:
+                delay(wait_us)
+        for i, p in enumerate(work):
+            if i == 2:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            eng.rebind(p)
+            bands.run_band_edge_first(hip, eng, topo, niter, fake_exchange, stream, side, torch)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    out["edge_first"] = {"what": "bands.run_band_edge_first: pass B of the band's first and last block row (one small launch) and the "
+                                 "halo exchange on a side stream, the interior rows on the main stream -- the exchange hides behind them",
+                         "ms_per_step": {}, "speedup_vs_1": {}}
     for n in (1, 2, 4, 8):
         if n == 1:
             topo = bands.BandTopology(0, 1, 0, hblk_total)
@@ -576,6 +601,7 @@ def _scaling_emulation(torch, hip, bands, full, quant, flags, niter, dev, hblk_t
         if n > 1:
             if delay:
                 out["exchange_latency_us"][str(n)] = {str(d): out["ms_per_step"]["1"] / time_band(src, topo, d)[0] for d in delays[1:]}
+            out["edge_first"]["ms_per_step"][str(n)] = {str(d): time_edge_first(src, topo, d) for d in (delays if delay else delays[:1])}
             r0, r1, e0, e1 = bands.deep_band_rows(hblk_total, n, n // 2, niter)
             dms, _ = time_band(full[e0:e1].contiguous(), bands.BandTopology(0, 1, e0, e1), 0, exchange=False)
             out["deep_halo"]["ms_per_step"][str(n)] = dms
@@ -584,6 +610,7 @@ def _scaling_emulation(torch, hip, bands, full, quant, flags, niter, dev, hblk_t
     for n in ("2", "4", "8"):
         out["speedup_vs_1"][n] = out["ms_per_step"]["1"] / out["ms_per_step"][n]
         out["deep_halo"]["speedup_vs_1"][n] = out["ms_per_step"]["1"] / out["deep_halo"]["ms_per_step"][n]
+        out["edge_first"]["speedup_vs_1"][n] = {d: out["ms_per_step"]["1"] / ms for d, ms in out["edge_first"]["ms_per_step"][n].items()}
     if not delay:
         out["exchange_latency_us"] = None
     return out
@@ -710,7 +737,7 @@ def run_luma(c):
     planes_identical = all(bool(torch.equal(work[-1][0], p)) for p in work[-1][1:])
 
     # ---- extra legs (not part of `value`) ------------------------------------------------------------------
-    single_plane_ms = value_batch1 = smooth_res = deep_res = None
+    single_plane_ms = value_batch1 = smooth_res = deep_res = edge_res = None
     if engs and not args.no_extras:
         # (1) ONE plane per step (batch = 1): the latency of a single image and, for N > 1, single-image strong scaling
         k1 = max(3, min(args.steps, 20))
@@ -759,6 +786,32 @@ def run_luma(c):
                         "rows_owned_and_held": [_r1 - _r0, e1 - e0], "equals_exchange_schedule": bool(flag.item()),
                         "what": "one image per step, every rank holds niter extra block rows per cut side and exchanges nothing"}
             del wd, deng
+        # (1c) N > 1: the single image on the latency-hiding schedule (bands.run_band_edge_first): edge rows + exchange on a
+        # side stream, interior rows on the main stream
+        if is_band and world > 1:
+            we = [pristine.clone() for _ in range(k1 + 2)]
+            eeng = bands.HipBandEngine(hip, torch, we[0], quant, flags, luma=1, device=dev)
+            side = torch.cuda.Stream(device=dev)
+
+            def one_edge_first(p):
+                eeng.rebind(p)
+                bands.run_band_edge_first(hip, eeng, topo, args.niter, lambda: exch(eeng, topo, dist), stream, side, torch)
+            for p in we[:2]:
+                one_edge_first(p)
+            _fence(torch, dist, world)
+            te = time.perf_counter()
+            for p in we[2:]:
+                one_edge_first(p)
+            _fence(torch, dist, world)
+            ee = _max_over_ranks(torch, dist, world, time.perf_counter() - te, dev, args.backend)
+            same = bool(torch.equal(we[-1], last))
+            flag = torch.tensor([int(same)], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            edge_res = {"single_plane_ms": ee / k1 * 1e3, "value_batch1": total_blocks_plane / (ee / k1),
+                        "equals_exchange_schedule": bool(flag.item()),
+                        "what": "one image per step; pass B of the band's first / last block row and the halo exchange on a side stream, "
+                                "the interior rows on the main stream (bands.run_band_edge_first)"}
+            del we, eeng
         # (2) N = 1: the same workload on the smooth variant of the image (what the wave-uniform need_refresh skip is
         # worth on content that is not sensor noise; the headline input never lets a whole wave skip)
         if world == 1 and args.input == "survey":
@@ -795,7 +848,7 @@ def run_luma(c):
                kernel_launches=len(ev_pairs),
                workload=f"{size}x{size} luma plane ({hblk_total * wblk} blocks)",
                planes_identical=planes_identical, single_plane_ms=single_plane_ms, value_batch1=value_batch1,
-               smooth_input=smooth_res, scaling_emulation=scaling_emu, deep_halo_schedule=deep_res)
+               smooth_input=smooth_res, scaling_emulation=scaling_emu, deep_halo_schedule=deep_res, edge_first_schedule=edge_res)
     if c["verify"] and c["sharded"]:
         from oracle.oracle import Oracle
         got = last.cpu().numpy()

@@ -287,6 +287,63 @@ def run_bands_batched_sets(hip, engines, topo: BandTopology, niter: int, exchang
                 e.plane, e.plane2 = e.plane2, e.plane
 
 
+def run_band_edge_first(hip, e, topo: BandTopology, niter: int, exchange, main, side, torch) -> None:
+    """ONE plane (a single image's band), latency-hiding schedule on the fused kernels (round 6).  Only the first and the last
+    block row of a band read the halo rows, and only they PRODUCE the rows the neighbours need.  Per iteration:
+        side stream:  pass B of block rows {0, hblk-1} as ONE two-plane set launch (32 groups at 8192 px: the small-plane
+                      kernel, ~80 us), then the halo exchange for the NEXT iteration's planes;
+        main stream:  pass B of the interior rows [1, hblk-1) (reads no halo row) -- the exchange hides behind it.
+    The three launch regions are VIEWS of the band's coefficient array and pixel planes (plane pointer + 8 * r * pitch: a
+    view's apron rows are the neighbouring region's real pixel rows, which is exactly what a block reads across its border),
+    so nothing is copied and the kernels are the unchanged plane-set kernels.  Iteration n + 1 starts when both kernels of
+    iteration n are done (events both ways); the exchange is ordered on the side stream behind the edge kernel that produced
+    its rows.  `exchange()` is called with the side stream current and must move the halo rows of `e.plane` (the plane the
+    coming pass B reads).  Bit-exact with run_bands_batched_sets; falls back to it for bands of fewer than 3 block rows."""
+    if e.hblk < 3:
+        return run_bands_batched_sets(hip, [e], topo, niter, exchange, stream=main.cuda_stream)
+    e.ensure_plane2()
+    band_top = 1 if topo.up is not None else 0          # the band's own top / bottom apron row is a halo row
+    band_bot = 2 if topo.down is not None else 0
+    pitch, wb, hb = e.pitch, e.wblk, e.hblk
+    row_bytes = wb * 128
+
+    def views(cur, nxt):
+        """(edge set, interior set) for planes cur -> nxt (nxt None on the last iteration)"""
+        c0, p0 = e.coef.data_ptr(), cur.data_ptr()
+        n0 = nxt.data_ptr() if nxt is not None else None
+        at = lambda base, r: base + r * 8 * pitch if base is not None else None
+        top = (e.cst.data_ptr(), c0, p0, e.status.data_ptr(), wb, 1, e.luma, band_top | 2, n0)
+        bot = (e.cst.data_ptr(), c0 + (hb - 1) * row_bytes, at(p0, hb - 1), e.status.data_ptr(), wb, 1, e.luma, 1 | band_bot, at(n0, hb - 1))
+        mid = (e.cst.data_ptr(), c0 + row_bytes, at(p0, 1), e.status.data_ptr(), wb, hb - 2, e.luma, 3, at(n0, 1))
+        return hip.plane_refs([top, bot]), hip.plane_refs([mid])
+    ev_main, ev_edge = torch.cuda.Event(), torch.cuda.Event()
+    whole = hip.plane_refs([(e.cst.data_ptr(), e.coef.data_ptr(), e.plane.data_ptr(), e.status.data_ptr(), wb, hb, e.luma, band_top | band_bot)])
+    hip.idct_planes(whole, True, main.cuda_stream)
+    ev_main.record(main)
+    side.wait_event(ev_main)
+    with torch.cuda.stream(side):
+        exchange()                                       # halo rows of the first planes
+    for it in range(niter):
+        last = it == niter - 1
+        edge, mid = views(e.plane, None if last else e.plane2)
+        # edge rows: behind the previous interior launch (their neighbours' pixels) and, in stream order, the exchange
+        if it:
+            side.wait_event(ev_main)
+        hip.smooth_planes(edge, e.flags, last, side.cuda_stream)
+        ev_edge_now = torch.cuda.Event(); ev_edge_now.record(side)
+        # interior rows: behind the previous EDGE launch (rows 0 and hblk-1 are their neighbours)
+        if it:
+            main.wait_event(ev_edge)
+        hip.smooth_planes(mid, e.flags, last, main.cuda_stream)
+        ev_main = torch.cuda.Event(); ev_main.record(main)
+        ev_edge = ev_edge_now
+        if not last:
+            e.plane, e.plane2 = e.plane2, e.plane
+            with torch.cuda.stream(side):
+                exchange()                               # rows of the new current plane, produced by the edge launch just queued
+    main.wait_event(ev_edge)
+
+
 def run_bands_batched_fused(engines, topo: BandTopology, niter: int, exchange_many) -> None:
     """The fused schedule for ANY engine that offers `smooth_next(final_clamp, write_next, rep_top, rep_bot)` (pass B that
     also writes the next iteration's pixel plane into the engine's second plane and swaps the two): pass A once, then

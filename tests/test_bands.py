@@ -334,6 +334,9 @@ def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
         # ... and the communication-avoiding schedule: same rows as the exchange schedule, without any exchange
         dh = d["deep_halo_schedule"]
         assert dh["equals_exchange_schedule"] is True and dh["value_batch1"] > 0 and dh["rows_owned_and_held"] == [64, 67]
+        # ... and the latency-hiding one (edge rows + exchange on a side stream, interior rows on the main stream)
+        ef = d["edge_first_schedule"]
+        assert ef["equals_exchange_schedule"] is True and ef["value_batch1"] > 0
 
 
 @pytest.mark.gpu
@@ -388,6 +391,28 @@ def test_deep_halo_bands_on_one_gpu_equal_unsharded(gpu, pkg, oracle, synth, nba
             parts.append(eng.coef[r0 - e0:r1 - e0].cpu().numpy())
         want = oracle.do_quantsmooth([coef], [quant], flags, niter, threads=8)["coefs"][0]
         assert np.array_equal(np.concatenate(parts, axis=0), want), f"flags={flags} niter={niter}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(264, 328), (1024, 2048), (520, 16)])
+def test_edge_first_schedule_whole_plane_equals_unsharded(gpu, pkg, oracle, synth, size):
+    """bands.run_band_edge_first on a band without neighbours (the whole plane): three VIEWS of one coefficient array and
+    one pair of pixel planes -- first block row, last block row, interior -- run as two concurrent launches per iteration
+    on two streams; image edges replicate.  Must equal the unsharded oracle (the two-rank form runs in
+    test_bench_sharded_path_two_processes_one_gpu); a two-row plane takes the fall-back."""
+    import torch
+    from jpeg_quantsmooth_amd import bands
+    coef, quant = synth.synth_gray(size[0], size[1], 50, seed=4)
+    dev = torch.device("cuda:0")
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream(device=dev)
+    topo = bands.BandTopology(0, 1, 0, coef.shape[0])
+    for flags, niter in ((0, 3), (1, 2), (16, 1)):
+        eng = bands.HipBandEngine(gpu, torch, torch.from_numpy(coef.copy()).to(dev), quant, flags)
+        bands.run_band_edge_first(gpu, eng, topo, niter, lambda: None, main, side, torch)
+        torch.cuda.synchronize()
+        assert not eng.bad_coef()
+        want = oracle.do_quantsmooth([coef], [quant], flags, niter, threads=8)["coefs"][0]
+        assert np.array_equal(eng.coef.cpu().numpy(), want), f"flags={flags} niter={niter}"
 
 
 @pytest.mark.gpu
