@@ -17,10 +17,14 @@
  * present but FAILS (out of memory, launch error) is never papered over with the CPU: the call reports
  * the failure, counts a libjpeg warning and leaves the image untouched.
  *
- * Build: cc -shared -fPIC jpegqs_shim.c qs_cpu.c -fopenmp -I<libjpeg include> -L.. -ljpegqs_hip
+ * Build: cc -shared -fPIC jpegqs_shim.c qs_cpu.c -fopenmp -I<libjpeg include> -ldl -lpthread   (libjpegqs_hip.so is
+ *        loaded at first use, see hip_lib() below)
  *        (no libjpeg symbols are needed unless TRANSCODE_ONLY is left undefined,
  *        in which case the four jinit_* entry points below come from libjpeg).
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE   /* dladdr */
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -33,6 +37,57 @@
 #include "qs_cpu.h"
 
 #define logfmt(...) fprintf(stderr, __VA_ARGS__)
+
+/* ---- the GPU library is loaded at first use, not linked ------------------------------------------------------------------
+ * libjpegqs_hip.so needs the HIP runtime (libamdhip64); a program linked against THIS library must still start -- and
+ * get its images smoothed by the CPU back end -- on a machine where that runtime is not installed at all.  So the six
+ * entry points used here are looked up with dlopen / dlsym: first the file named by QS_HIP_LIB (A/B builds), then
+ * libjpegqs_hip.so next to this library (found through dladdr), then by name through the loader's search path. */
+#include <dlfcn.h>
+#include <pthread.h>
+static struct {
+	int ok;
+	char why[256];
+	int (*do_rows)(qs_hip_job *, int16_t *const *const *, int, int, int, qs_hip_progress_fn, void *);
+	int (*do_flat)(qs_hip_job *, int, int, int, qs_hip_progress_fn, void *);
+	int (*prewarm)(const qs_hip_job *, int, int);
+	int (*device_count)(void);
+	const char *(*last_error)(void);
+	void (*free_)(void *);
+} H;
+static pthread_once_t hip_once = PTHREAD_ONCE_INIT;
+static void hip_load_once(void) {
+	void *h = NULL;
+	const char *over = getenv("QS_HIP_LIB");
+	Dl_info me;
+	char path[4096];
+	if (over && *over) h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+	if (!h && dladdr((void *)&hip_load_once, &me) && me.dli_fname) {
+		const char *slash = strrchr(me.dli_fname, '/');
+		size_t n = slash ? (size_t)(slash - me.dli_fname) + 1 : 0;
+		if (n + sizeof("libjpegqs_hip.so") < sizeof(path)) {
+			memcpy(path, me.dli_fname, n);
+			strcpy(path + n, "libjpegqs_hip.so");
+			h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+		}
+	}
+	if (!h) h = dlopen("libjpegqs_hip.so", RTLD_NOW | RTLD_LOCAL);
+	if (!h) {
+		const char *e = dlerror();
+		snprintf(H.why, sizeof(H.why), "the GPU library could not be loaded (%s)", e ? e : "dlopen failed");
+		return;
+	}
+	*(void **)&H.do_rows = dlsym(h, "qs_hip_do_quantsmooth_rows");
+	*(void **)&H.do_flat = dlsym(h, "qs_hip_do_quantsmooth");
+	*(void **)&H.prewarm = dlsym(h, "qs_hip_prewarm");
+	*(void **)&H.device_count = dlsym(h, "qs_hip_device_count");
+	*(void **)&H.last_error = dlsym(h, "qs_hip_last_error");
+	*(void **)&H.free_ = dlsym(h, "qs_hip_free");
+	H.ok = H.do_rows && H.do_flat && H.prewarm && H.device_count && H.last_error && H.free_;
+	if (!H.ok) snprintf(H.why, sizeof(H.why), "the GPU library lacks an entry point of include/jpegqs_hip.h");
+}
+static int hip_lib(void) { pthread_once(&hip_once, hip_load_once); return H.ok; }
+static int hip_device_count(void) { return hip_lib() ? H.device_count() : 0; }
 
 #ifndef TRANSCODE_ONLY
 /* libjpeg-internal entry points used to re-arm the decompressor after the
@@ -67,7 +122,8 @@ static int use_cpu_backend(const char **why) {
 	if (e && !strcmp(e, "hip")) return 0;
 	if (e && !strcmp(e, "cpu")) { *why = "JPEGQS_BACKEND=cpu"; return 1; }
 	if (f && *f && strcmp(f, "0")) { *why = "QS_HIP_FORCE_CPU is set"; return 1; }
-	if (qs_hip_device_count() <= 0) { *why = "no HIP device visible"; return 1; }
+	if (!hip_lib()) { *why = H.why; return 1; }
+	if (hip_device_count() <= 0) { *why = "no HIP device visible"; return 1; }
 	return 0;
 }
 
@@ -82,7 +138,7 @@ static __thread int16_t *qs_copy[QS_HIP_MAXC] = { NULL, NULL, NULL, NULL };
 static void release_parked(void) {
 	int j;
 	for (j = 0; j < 2; j++) if (qs_parked[j]) {
-		if (qs_parked_cpu) qs_cpu_free(qs_parked[j]); else qs_hip_free(qs_parked[j]);
+		if (qs_parked_cpu) qs_cpu_free(qs_parked[j]); else if (hip_lib()) H.free_(qs_parked[j]);
 		qs_parked[j] = NULL;
 	}
 	for (j = 0; j < QS_HIP_MAXC; j++) if (qs_copy[j]) { free(qs_copy[j]); qs_copy[j] = NULL; }
@@ -94,7 +150,8 @@ static void release_parked(void) {
 void jpegqs_hip_prewarm(j_decompress_ptr cinfo, jpegqs_control_t *opts) {
 	qs_hip_job g;
 	int ci, i;
-	if (!cinfo || !opts) { (void)qs_hip_prewarm(NULL, 0, 0); return; }
+	if (!hip_lib()) return;
+	if (!cinfo || !opts) { (void)H.prewarm(NULL, 0, 0); return; }
 	if (opts->niter <= 0 && !(opts->flags & JPEGQS_UPSAMPLE_UV)) return;   /* the early-out of reference :2458 needs no device */
 	if (cinfo->num_components < 1 || cinfo->num_components > QS_HIP_MAXC) return;
 	memset(&g, 0, sizeof(g));
@@ -111,7 +168,7 @@ void jpegqs_hip_prewarm(j_decompress_ptr cinfo, jpegqs_control_t *opts) {
 		g.has_quant[ci] = tbl != NULL;
 		if (tbl) for (i = 0; i < DCTSIZE2; i++) g.quant[ci][i] = tbl->quantval[i];
 	}
-	(void)qs_hip_prewarm(&g, opts->flags & JPEGQS_FLAGS_MASK, opts->niter);
+	(void)H.prewarm(&g, opts->flags & JPEGQS_FLAGS_MASK, opts->niter);
 }
 
 static double now_ms(void) {
@@ -170,7 +227,7 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 	if (have_work) on_cpu = use_cpu_backend(&why_cpu);
 	if (flags & JPEGQS_INFO_CPU) {                  /* the reference's dispatcher prints its choice here (libjpegqs.c:141-145) */
 		if (on_cpu) logfmt("SIMD type: cpu back end (%s; %d blocks per vector, %s)\n", why_cpu, qs_cpu_lanes(), qs_cpu_isa());
-		else logfmt("SIMD type: hip/gfx950 (%d device(s))\n", qs_hip_device_count());
+		else logfmt("SIMD type: hip/gfx950 (%d device(s))\n", hip_device_count());
 	}
 	if (on_cpu) {
 		/* never silent: once per process, whatever the --info bits say */
@@ -268,14 +325,19 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 		if (ret < 0) logfmt("jpegqs: the CPU back end rejected the image (code %d)\n", ret);
 		else qs_backend_name = "cpu";
 	} else {
-		if (in_place)
-			ret = qs_hip_do_quantsmooth_rows(&job, (int16_t *const *const *)rows, flags & JPEGQS_FLAGS_MASK,
-					opts->niter, opts->progprec, opts->progress, opts->userdata);
-		else
-			ret = qs_hip_do_quantsmooth(&job, flags & JPEGQS_FLAGS_MASK, opts->niter, opts->progprec,
-					opts->progress, opts->userdata);
-		if (ret < 0) logfmt("jpegqs-hip: %s\n", qs_hip_last_error());
-		else if (have_work) qs_backend_name = "hip";
+		if (!hip_lib()) {                            /* (JPEGQS_BACKEND=hip on a machine without the GPU library) */
+			ret = QS_HIP_ENODEV;
+			logfmt("jpegqs-hip: no HIP device: %s\n", H.why);
+		} else {
+			if (in_place)
+				ret = H.do_rows(&job, (int16_t *const *const *)rows, flags & JPEGQS_FLAGS_MASK,
+						opts->niter, opts->progprec, opts->progress, opts->userdata);
+			else
+				ret = H.do_flat(&job, flags & JPEGQS_FLAGS_MASK, opts->niter, opts->progprec,
+						opts->progress, opts->userdata);
+			if (ret < 0) logfmt("jpegqs-hip: %s\n", H.last_error());
+		}
+		if (ret >= 0 && have_work) qs_backend_name = "hip";
 	}
 	if (ret < 0) {
 		/* A back end that FAILED left the image untouched; callers written against the reference only see
@@ -332,7 +394,7 @@ int do_quantsmooth(j_decompress_ptr srcinfo, jvirt_barray_ptr *coef_arrays, jpeg
 						((j_common_ptr)srcinfo, up[ci], blk_y, 1, TRUE);
 				memcpy(buf[0], (char*)job.coef_up[ci] + rowbytes * blk_y, rowbytes);
 			}
-			if (on_cpu) qs_cpu_free(job.coef_up[ci]); else qs_hip_free(job.coef_up[ci]);
+			if (on_cpu) qs_cpu_free(job.coef_up[ci]); else H.free_(job.coef_up[ci]);
 			qs_parked[ci] = NULL;
 			coef_arrays[ci + 1] = up[ci];
 			srcinfo->comp_info[ci + 1].width_in_blocks = uw;

@@ -238,3 +238,25 @@ def test_reference_example_program_on_the_library_without_a_gpu(tmp_path):
         if a.exists():
             assert a.read_bytes() == b.read_bytes(), src
             a.unlink(); b.unlink()
+
+
+def test_program_linked_against_libjpegqs_alone_runs_without_the_gpu_library(tmp_path):
+    """libjpegqs.so does not LINK the GPU library (which needs the HIP runtime): it loads libjpegqs_hip.so from its own
+    directory at first use.  A copy of the CLI and the library in a directory WITHOUT libjpegqs_hip.so stands for a machine
+    where no HIP runtime is installed: the program starts, says why the CPU back end runs, and writes the reference's bytes;
+    JPEGQS_BACKEND=hip makes it the error it then is."""
+    import shutil
+    for f in ("libjpegqs.so", "jpegqs"):
+        shutil.copy2(PKG / f, tmp_path / f)
+    needed = subprocess.run(["readelf", "-d", str(tmp_path / "libjpegqs.so")], capture_output=True, text=True).stdout
+    assert "libjpegqs_hip" not in needed and "libamdhip64" not in needed
+    out = tmp_path / "o.jpg"
+    env = {k: v for k, v in os.environ.items() if k not in ("JPEGQS_BACKEND", "QS_HIP_FORCE_CPU", "QS_HIP_LIB", "LD_LIBRARY_PATH")}
+    r = subprocess.run([str(tmp_path / "jpegqs"), "-q", "6", "-i", "0", str(GOLD / "rgb141x93_420.jpg"), str(out)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "the GPU library could not be loaded" in r.stderr and "using the CPU back end" in r.stderr
+    assert out.read_bytes() == (GOLD / "rgb141x93_420.q6.ref.jpg").read_bytes()
+    out.unlink()
+    r = subprocess.run([str(tmp_path / "jpegqs"), "-q", "3", "-i", "0", str(GOLD / "gray64.jpg"), str(out)], capture_output=True, text=True,
+                       env=dict(env, JPEGQS_BACKEND="hip"))
+    assert r.returncode == 3 and not out.exists() and "could not be loaded" in r.stderr
