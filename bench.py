@@ -139,6 +139,9 @@ def parse_args():
     ap.add_argument("--verify", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="torch.distributed backend (gloo: functional test of the sharded path)")
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (functional test of the sharded path on a 1-GPU box, with --backend gloo)")
+    ap.add_argument("--edge-first", action="store_true",
+                    help="N > 1: also time the single image on the latency-hiding band schedule (bands.run_band_edge_first): edge rows + "
+                         "exchange on a side stream, interior rows on the main stream")
     ap.add_argument("--print-kernel-hash", action="store_true", help="print kernel_sources_sha1() (what profiles/pmc_traffic.json is tied to) and exit")
     a = ap.parse_args()
     if a.print_kernel_hash:
@@ -762,56 +765,62 @@ def run_luma(c):
         # (1b) N > 1: the same single image on the COMMUNICATION-AVOIDING schedule: every rank runs its band plus niter block
         # rows per cut side, nothing is exchanged during the iterations (csrc/qs_shard.cpp: qs_hip_set_shard_schedule(1));
         # its owned rows must equal what the exchange schedule produced
-        if deep_src is not None and world > 1:
-            _r0, _r1, e0, e1 = deep_rows
-            wd = [deep_src.clone() for _ in range(k1 + 2)]
-            deng = bands.HipBandEngine(hip, torch, wd[0], quant, flags, luma=1, device=dev)
+        def timed_single(run_one, inputs):
+            """k1 steps of one image each, timed like value_batch1 -> (seconds, the last result tensor)"""
+            for p in inputs[:2]:
+                run_one(p)
+            _fence(torch, dist, world)
+            t = time.perf_counter()
+            for p in inputs[2:]:
+                run_one(p)
+            _fence(torch, dist, world)
+            return _max_over_ranks(torch, dist, world, time.perf_counter() - t, dev, args.backend), inputs[-1]
+
+        def all_ranks_agree(ok):
+            flag = torch.tensor([int(ok)], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+
+        def leg_deep():
+            o0, o1, e0, e1 = deep_rows
+            deng = bands.HipBandEngine(hip, torch, deep_src, quant, flags, luma=1, device=dev)
             dtopo = bands.BandTopology(0, 1, e0, e1)
 
-            def one_deep(p):
+            def one(p):
                 deng.rebind(p)
                 bands.run_bands_batched_sets(hip, [deng], dtopo, args.niter, lambda: None)
-            for p in wd[:2]:
-                one_deep(p)
-            _fence(torch, dist, world)
-            td = time.perf_counter()
-            for p in wd[2:]:
-                one_deep(p)
-            _fence(torch, dist, world)
-            ed = _max_over_ranks(torch, dist, world, time.perf_counter() - td, dev, args.backend)
-            same = bool(torch.equal(wd[-1][_r0 - e0:_r1 - e0], last))
-            flag = torch.tensor([int(same)], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            deep_res = {"single_plane_ms": ed / k1 * 1e3, "value_batch1": total_blocks_plane / (ed / k1),
-                        "rows_owned_and_held": [_r1 - _r0, e1 - e0], "equals_exchange_schedule": bool(flag.item()),
-                        "what": "one image per step, every rank holds niter extra block rows per cut side and exchanges nothing"}
-            del wd, deng
-        # (1c) N > 1: the single image on the latency-hiding schedule (bands.run_band_edge_first): edge rows + exchange on a
-        # side stream, interior rows on the main stream
-        if is_band and world > 1:
-            we = [pristine.clone() for _ in range(k1 + 2)]
-            eeng = bands.HipBandEngine(hip, torch, we[0], quant, flags, luma=1, device=dev)
+            sec, res = timed_single(one, [deep_src.clone() for _ in range(k1 + 2)])
+            return {"single_plane_ms": sec / k1 * 1e3, "value_batch1": total_blocks_plane / (sec / k1),
+                    "rows_owned_and_held": [o1 - o0, e1 - e0],
+                    "equals_exchange_schedule": all_ranks_agree(torch.equal(res[o0 - e0:o1 - e0], last)),
+                    "what": "one image per step, every rank holds niter extra block rows per cut side and exchanges nothing"}
+
+        def leg_edge_first():
+            eeng = bands.HipBandEngine(hip, torch, pristine, quant, flags, luma=1, device=dev)
             side = torch.cuda.Stream(device=dev)
 
-            def one_edge_first(p):
+            def one(p):
                 eeng.rebind(p)
                 bands.run_band_edge_first(hip, eeng, topo, args.niter, lambda: exch(eeng, topo, dist), stream, side, torch)
-            for p in we[:2]:
-                one_edge_first(p)
-            _fence(torch, dist, world)
-            te = time.perf_counter()
-            for p in we[2:]:
-                one_edge_first(p)
-            _fence(torch, dist, world)
-            ee = _max_over_ranks(torch, dist, world, time.perf_counter() - te, dev, args.backend)
-            same = bool(torch.equal(we[-1], last))
-            flag = torch.tensor([int(same)], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            edge_res = {"single_plane_ms": ee / k1 * 1e3, "value_batch1": total_blocks_plane / (ee / k1),
-                        "equals_exchange_schedule": bool(flag.item()),
-                        "what": "one image per step; pass B of the band's first / last block row and the halo exchange on a side stream, "
-                                "the interior rows on the main stream (bands.run_band_edge_first)"}
-            del we, eeng
+            sec, res = timed_single(one, [pristine.clone() for _ in range(k1 + 2)])
+            return {"single_plane_ms": sec / k1 * 1e3, "value_batch1": total_blocks_plane / (sec / k1),
+                    "equals_exchange_schedule": all_ranks_agree(torch.equal(res, last)),
+                    "what": "one image per step; pass B of the band's first / last block row and the halo exchange on a side stream, "
+                            "the interior rows on the main stream (bands.run_band_edge_first)"}
+        # (an extra leg must not cost the headline line: a failure is recorded, the run goes on)
+        if deep_src is not None and world > 1:
+            try:
+                deep_res = leg_deep()
+            except Exception as ex:  # noqa: BLE001
+                deep_res = {"error": repr(ex)[:300]}
+        # (1c) N > 1, opt-in (--edge-first): the single image on the latency-hiding schedule.  It issues RCCL operations from a
+        # second stream next to running kernels -- a pattern nothing in this repository has met real links with:
+        # tools/first_contact.sh asks for it, the driver's plain command does not.
+        if is_band and world > 1 and args.edge_first:
+            try:
+                edge_res = leg_edge_first()
+            except Exception as ex:  # noqa: BLE001
+                edge_res = {"error": repr(ex)[:300]}
         # (2) N = 1: the same workload on the smooth variant of the image (what the wave-uniform need_refresh skip is
         # worth on content that is not sensor noise; the headline input never lets a whole wave skip)
         if world == 1 and args.input == "survey":

@@ -298,7 +298,7 @@ def test_plane_rows_exchange_gloo(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--overlap", "--no-extras"], ["--backend", "nccl", "--no-extras"]])
+@pytest.mark.parametrize("extra", [["--edge-first"], ["--overlap", "--no-extras"], ["--backend", "nccl", "--no-extras"]])
 def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one
     process per rank, band split, comm side stream, overlapped schedule), but on ONE
@@ -323,7 +323,7 @@ def test_bench_sharded_path_two_processes_one_gpu(gpu, extra):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["verify_band_edges_ok"] is True and d["verify_ok"] is True
-    if not extra:
+    if "--no-extras" not in extra:
         # the extra legs: single-plane steps over the same bands, and the product's own route
         # (qs_hip_do_quantsmooth_sharded over two logical devices) run as a child process of rank 0
         assert d["single_plane_ms"] > 0 and d["value_batch1"] > 0 and d["planes_identical"] is True

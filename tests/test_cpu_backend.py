@@ -260,3 +260,22 @@ def test_program_linked_against_libjpegqs_alone_runs_without_the_gpu_library(tmp
     r = subprocess.run([str(tmp_path / "jpegqs"), "-q", "3", "-i", "0", str(GOLD / "gray64.jpg"), str(out)], capture_output=True, text=True,
                        env=dict(env, JPEGQS_BACKEND="hip"))
     assert r.returncode == 3 and not out.exists() and "could not be loaded" in r.stderr
+
+
+@pytest.mark.parametrize("what", ["2048x2048 luma q3", "2048x2048 luma q4", "1920x1080 4:2:0 q6 n3", "1920x1080 4:4:4 q5 n2"])
+def test_cpu_backend_larger_images_every_block(cpu, reference, synth, what):
+    """sizes where every OpenMP thread gets many block rows and every lane group is full: every block against the
+    compiled reference (scalar build, 8 threads)"""
+    if "luma" in what:
+        coef, quant = synth.synth_gray(2048, 2048, 50)
+        flags = 1 if what.endswith("q4") else 0
+        want = reference.do_quantsmooth([coef], [quant], flags, 3, threads=8)
+        got = cpu.do_quantsmooth([coef], [quant], flags, 3, by_rows=True)
+    else:
+        hs = 2 if "4:2:0" in what else 1
+        j = synth.synth_ycc(1920, 1080, hs, hs, quality=50, seed=11)
+        kw = dict(hsamp=j["hsamp"], vsamp=j["vsamp"], colorspace=3, image_size=(1920, 1080))
+        flags, niter = (7, 3) if hs == 2 else (3, 2)
+        want = reference.do_quantsmooth(j["coefs"], j["quants"], flags, niter, threads=8, **kw)
+        got = cpu.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
+    assert_same_result(got, want, what)

@@ -51,7 +51,7 @@ done
 # (c) the RCCL band driver: q3 (12 planes per step, then one), q6
 for n in $NS; do
   [ "$n" -ge 2 ] || continue
-  step "c_bench_q3_n$n" 900 python bench.py --gpus "$n" --steps 10 --warmup 3 --no-cpu-baseline || FAILS=$((FAILS + 1))
+  step "c_bench_q3_n$n" 900 python bench.py --gpus "$n" --steps 10 --warmup 3 --no-cpu-baseline --edge-first || FAILS=$((FAILS + 1))
   step "c_bench_q3_batch1_n$n" 900 python bench.py --gpus "$n" --steps 20 --warmup 3 --batch 1 --no-cpu-baseline --no-extras || FAILS=$((FAILS + 1))
   step "c_bench_q6_n$n" 900 python bench.py --gpus "$n" --quality 6 --steps 5 --warmup 2 --no-cpu-baseline || FAILS=$((FAILS + 1))
   for f in c_bench_q3_n$n c_bench_q3_batch1_n$n c_bench_q6_n$n; do
@@ -65,7 +65,8 @@ else:
     print(f"      value {d['value'] / 1e6:.1f} M blocks/s, ms/step {d['ms_per_step']:.2f}, n_gpus {d['n_gpus']}, rccl_ranks {d['config'].get('rccl_ranks')}, "
           f"verify_ok {d.get('verify_ok')}, band edges {d.get('verify_band_edges_ok')}, value_batch1 {d.get('value_batch1')}, "
           f"product_route {(d.get('product_route') or {}).get('ms_per_image')}, "
-          f"deep-halo schedule batch1 {(d.get('deep_halo_schedule') or {}).get('value_batch1')} (equal: {(d.get('deep_halo_schedule') or {}).get('equals_exchange_schedule')})")
+          f"deep-halo schedule batch1 {(d.get('deep_halo_schedule') or {}).get('value_batch1')} (equal: {(d.get('deep_halo_schedule') or {}).get('equals_exchange_schedule')}), "
+          f"edge-first schedule batch1 {(d.get('edge_first_schedule') or {}).get('value_batch1')} (equal: {(d.get('edge_first_schedule') or {}).get('equals_exchange_schedule')})")
 PY
   done
 done
