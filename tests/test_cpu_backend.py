@@ -279,3 +279,29 @@ def test_cpu_backend_larger_images_every_block(cpu, reference, synth, what):
         want = reference.do_quantsmooth(j["coefs"], j["quants"], flags, niter, threads=8, **kw)
         got = cpu.do_quantsmooth(j["coefs"], j["quants"], flags, niter, **kw)
     assert_same_result(got, want, what)
+
+
+def test_cpu_backend_replays_the_committed_fuzz_corpus(cpu):
+    """tests/golden/fuzz_s2.jsonl (400 trials / 959 jobs up to 1400 x 1050, every flags value, batches taken job by job):
+    the hashes in it are the compiled reference's (tests/test_oracle.py re-derives the file from oracle/_ref) -- the CPU
+    back end must reproduce every one of them"""
+    import hashlib
+    import json
+    import sys
+    sys.argv = ["fuzz_gpu.py", "import-only", "-"]
+    import importlib.util
+    src = (ROOT / "tools" / "fuzz_gpu.py").read_text().split('if mode == "gen":')[0]     # the generators only
+    ns = {"__file__": str(ROOT / "tools" / "fuzz_gpu.py")}
+    exec(compile(src, "fuzz_gpu_generators", "exec"), ns)
+    trial_jobs, digest, kwargs = ns["trial_jobs"], ns["digest"], ns["kwargs"]
+    bad = jobs = 0
+    for line in open(ROOT / "tests" / "golden" / "fuzz_s2.jsonl"):
+        rec = json.loads(line)
+        made, flags, niter, _batch = trial_jobs(rec["seed0"], rec["trial"])
+        for (j, desc), want in zip(made, rec["expect"]):
+            got = cpu.do_quantsmooth(j["coefs"], j["quants"], flags & 0x3f, niter, by_rows=bool(jobs & 1), **kwargs(j))
+            jobs += 1
+            if digest(got) != want:
+                bad += 1
+                print("MISMATCH", rec["trial"], desc, flags, niter)
+    assert jobs == 959 and bad == 0
