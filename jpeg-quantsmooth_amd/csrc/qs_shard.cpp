@@ -357,10 +357,53 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
   struct ItEv { int dev; hipEvent_t e; };
   std::vector<ItEv> it_ev;
   struct ItEvFree { std::vector<ItEv>& v; ~ItEvFree() { for (ItEv& x : v) { (void)hipSetDevice(x.dev); (void)hipEventDestroy(x.e); } } } it_ev_free{it_ev};
+  // Progress (reference :2656-2664): the bands advance in lock step, so "iteration it of every component" is what
+  // completes; the calls whose share of the work that covers are made, in the reference's sequence, when the LAST band
+  // has finished the iteration.  With a callback installed the enqueue below stays at most ONE iteration ahead of what has
+  // been reported, so that a cancel stops further launches instead of letting the whole job run on every GPU first
+  // (ADVICE round 5).  A cancel ends like a tripped range check: the host input is untouched, the caller re-runs the job
+  // in the reference's order with the recorded answers (ProgressPlan::replay).
+  long long per_iter = 0;
+  for (int ci = 0; ci < job->ncomp; ++ci) per_iter += (long long)job->hblk[ci] * job->vsamp[ci];
+  int reported = 0;                                          // iterations whose progress calls have been made
+  bool tripped = false;
+  auto report_upto = [&](int upto) -> int {                  // make the calls of iterations [reported, upto)
+    const size_t nb = bands.b.size();
+    if (reported == 0 && upto > 0) {                         // every band's range check before the first call
+      for (Band& B : bands.b) {
+        HIP_TRY(hipSetDevice(B.dev));
+        HIP_TRY(hipEventSynchronize(B.evS));
+        const int32_t* h0 = static_cast<const int32_t*>(B.hstatus0.p);
+        for (size_t i = 0; i < B.planes.size(); ++i) tripped |= h0[i] != 0;
+      }
+      if (tripped) return QS_HIP_OK;                         // no call made: the careful route makes them live
+    }
+    for (; reported < upto && !plan->cancelled; ++reported) {
+      for (size_t d = 0; d < nb; ++d) {
+        const ItEv& x = it_ev[(size_t)reported * nb + d];
+        HIP_TRY(hipSetDevice(x.dev));
+        HIP_TRY(hipEventSynchronize(x.e));
+      }
+      // the callback runs on the caller's device, whatever band was synchronised last (it may use HIP / torch itself)
+      HIP_TRY(hipSetDevice(bands.home));
+      plan->advance(per_iter * (reported + 1));
+    }
+    return QS_HIP_OK;
+  };
+  auto abandon = [&](const char* why) -> int {              // drain every band; nothing has reached caller memory
+    for (Band& B : bands.b) { HIP_TRY(hipSetDevice(B.dev)); HIP_TRY(hipStreamSynchronize(B.s)); }
+    if (trace_on()) fprintf(stderr, "qs_hip trace: sharded(set) %s\n", why);
+    return JOB_RERUN_CAREFUL;
+  };
   // Pass A runs once; every pass B but the last writes the next iteration's pixel planes itself (fused pass A) into
   // the band's second set of planes -- plane (it & 1) is read, plane ((it + 1) & 1) written.
   for (int it = 0; it < niter; ++it) {
     const int cur = it & 1;
+    if (plan && it >= 2) {                                   // iteration it - 2 must have been reported before it is queued
+      if (int r = report_upto(it - 1)) return r;
+      if (tripped) return abandon("range check tripped");
+      if (plan->cancelled) return abandon("cancelled by the progress callback");
+    }
     if (it == 0)
       for (size_t d = 0; d < bands.b.size(); ++d) {
         Band& B = bands.b[d];
@@ -419,38 +462,9 @@ static int run_sharded_set(qs_hip_job* job, int flags, int niter, const std::vec
   const double t_enq = wall_ms();
 
   if (plan) {
-    // Progress (reference :2656-2664): the bands advance in lock step, so "iteration it of every component" is what
-    // completes; the calls whose share of the work that covers are made, in the reference's sequence, when the LAST
-    // band has finished the iteration.  A cancel ends like a tripped range check: the host input is untouched, the
-    // caller re-runs the job in the reference's order with the recorded answers (ProgressPlan::replay).
-    long long per_iter = 0;
-    for (int ci = 0; ci < job->ncomp; ++ci) per_iter += (long long)job->hblk[ci] * job->vsamp[ci];
-    const size_t nb = bands.b.size();
-    for (Band& B : bands.b) {                                // every band's range check before the first call
-      HIP_TRY(hipSetDevice(B.dev));
-      HIP_TRY(hipEventSynchronize(B.evS));
-      const int32_t* h0 = static_cast<const int32_t*>(B.hstatus0.p);
-      for (size_t i = 0; i < B.planes.size(); ++i)
-        if (h0[i]) {
-          for (Band& C : bands.b) { HIP_TRY(hipSetDevice(C.dev)); HIP_TRY(hipStreamSynchronize(C.s)); }
-          return JOB_RERUN_CAREFUL;                          // host input untouched, no call made: the careful route makes them live
-        }
-    }
-    for (int it = 0; it < niter && !plan->cancelled; ++it) {
-      for (size_t d = 0; d < nb; ++d) {
-        const ItEv& x = it_ev[(size_t)it * nb + d];
-        HIP_TRY(hipSetDevice(x.dev));
-        HIP_TRY(hipEventSynchronize(x.e));
-      }
-      // the callback runs on the caller's device, whatever band was synchronised last (it may use HIP / torch itself)
-      HIP_TRY(hipSetDevice(bands.home));
-      plan->advance(per_iter * (it + 1));
-    }
-    if (plan->cancelled) {
-      for (Band& B : bands.b) { HIP_TRY(hipSetDevice(B.dev)); HIP_TRY(hipStreamSynchronize(B.s)); }
-      if (trace_on()) fprintf(stderr, "qs_hip trace: sharded(set) cancelled by the progress callback\n");
-      return JOB_RERUN_CAREFUL;
-    }
+    if (int r = report_upto(niter)) return r;
+    if (tripped) return abandon("range check tripped");
+    if (plan->cancelled) return abandon("cancelled by the progress callback");
   }
   bool bad = false;
   if (int r = read_flags(bands, bad)) return r;
