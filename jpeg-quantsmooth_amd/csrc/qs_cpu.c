@@ -97,7 +97,7 @@ static inline void quant_interval(int coef, int div, int *mid, int *lo, int *hi)
 #define DEF_IDCT8(NAME, T) \
 static inline __attribute__((always_inline)) void NAME(const T *in, T *out) { \
 	T s = (in[2] + in[6]) * 4433, e2 = s - in[6] * 15137, e3 = s + in[2] * 6270; \
-	T e0 = (in[0] + in[4]) << 13, e1 = (in[0] - in[4]) << 13; \
+	T e0 = (in[0] + in[4]) * 8192, e1 = (in[0] - in[4]) * 8192; \
 	T b0 = e0 + e3, b3 = e0 - e3, b1 = e1 + e2, b2 = e1 - e2; \
 	T t0 = in[7], t1 = in[5], t2 = in[3], t3 = in[1]; \
 	T z1 = t0 + t3, z2 = t1 + t2, z3 = t0 + t2, z4 = t1 + t3, z5 = (z3 + z4) * 9633; \

@@ -305,3 +305,41 @@ def test_cpu_backend_replays_the_committed_fuzz_corpus(cpu):
                 bad += 1
                 print("MISMATCH", rec["trial"], desc, flags, niter)
     assert jobs == 959 and bad == 0
+
+
+_SANITIZER_CODE = r"""
+import sys, ctypes as C
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from helpers import golden_names, load_golden, assert_same_result
+from cpu_backend import CpuBackend
+import jpegqs_pkg
+alt = CpuBackend.__new__(CpuBackend); alt.lib = C.CDLL(sys.argv[1]); CpuBackend._bind(alt)
+for name in golden_names():
+    job, want = load_golden(name)
+    for by_rows in (False, True):
+        assert_same_result(alt.do_quantsmooth(job["coefs"], job["quants"], job["flags"], job["niter"], by_rows=by_rows, threads=2, **job["kw"]), want, name)
+synth = jpegqs_pkg.load().synth
+for (w, h, hs, vs) in ((17, 9, 2, 2), (8, 8, 1, 1), (333, 517, 2, 2), (100, 60, 4, 1), (64, 200, 1, 2)):
+    y = synth.synth_ycc(w, h, hs, vs, quality=40, seed=3)
+    for flags in (0, 1, 7, 15, 3, 11):
+        alt.do_quantsmooth(y["coefs"], y["quants"], flags, 2, hsamp=y["hsamp"], vsamp=y["vsamp"], colorspace=3, image_size=(w, h), threads=2)
+print("SANITIZERS_CLEAN")
+"""
+
+
+def test_cpu_backend_under_address_and_ub_sanitizers(tmp_path):
+    """csrc/qs_cpu.c built with -fsanitize=address,undefined (CPU build: the only place sanitizers are available) through
+    every golden in both calling forms and a set of odd geometries (17 x 9 4:2:0, 4:1:1, 4:4:0, one block): no report"""
+    import sys
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    ubsan = subprocess.run(["gcc", "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
+    if not (os.path.isabs(asan) and os.path.exists(asan) and os.path.isabs(ubsan) and os.path.exists(ubsan)):
+        pytest.skip("no libasan / libubsan next to gcc")
+    so = tmp_path / "qs_cpu_san.so"
+    subprocess.run(["gcc", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-fwrapv", "-fopenmp", "-fsanitize=address,undefined",
+                    "-fno-sanitize-recover=undefined", "-DQS_CPU_NO_CLONES", "-o", str(so), str(CSRC / "qs_cpu.c"), "-lm"], check=True)
+    env = dict(os.environ, LD_PRELOAD=f"{asan}:{ubsan}", ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, "-c", _SANITIZER_CODE % (str(ROOT), str(ROOT / "tests")), str(so)], capture_output=True, text=True,
+                       env=env, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0 and "SANITIZERS_CLEAN" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
