@@ -130,10 +130,25 @@ def test_multigpu_first_contact_script_runs_on_this_box(gpu, tmp_path):
 
 def _rccl():
     import ctypes as C
-    try:
-        lib = C.CDLL("librccl.so.1", mode=os.RTLD_GLOBAL)
-    except OSError:
-        pytest.skip("librccl.so.1 is not loadable on this box")
+    import importlib.util
+    # ONE RCCL (and one HIP runtime) per process: a PyTorch wheel bundles its own librccl.so next to its own libamdhip64;
+    # loading /opt/rocm's copy first and torch's later ends in a double free at exit.  Take torch's when torch is installed.
+    cand = []
+    spec = importlib.util.find_spec("torch")
+    if spec and spec.origin:
+        cand.append(str(Path(spec.origin).parent / "lib" / "librccl.so"))
+    cand += ["librccl.so.1", "librccl.so"]
+    lib = None
+    for name in cand:
+        if name.startswith("/") and not Path(name).exists():
+            continue
+        try:
+            lib = C.CDLL(name, mode=os.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if lib is None:
+        pytest.skip("librccl is not loadable on this box")
     lib.ncclCommInitAll.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
     lib.ncclCommDestroy.argtypes = [C.c_void_p]
     return lib
