@@ -194,10 +194,16 @@ def test_multigpu_rccl_band_entry_real_devices(gpu, synth, oracle):
     import ctypes as C
     import threading
     import numpy as np
-    import torch
     if _ndev(gpu) < 2:
         pytest.skip(f"needs >= 2 HIP devices, {_ndev(gpu)} visible")
     rccl = _rccl()
+    # the HIP runtime this process already uses (no torch here: importing it AFTER a communicator has lived in the process
+    # ended in a double free at interpreter exit on the one-GPU box)
+    try:
+        hip_rt = C.CDLL(None); hip_rt.hipSetDevice
+    except (OSError, AttributeError):
+        hip_rt = C.CDLL("libamdhip64.so")
+    hip_rt.hipSetDevice.argtypes = [C.c_int]
     n = _counts(gpu)[-1]
     comms = (C.c_void_p * n)()
     devs = (C.c_int * n)(*range(n))
@@ -210,7 +216,7 @@ def test_multigpu_rccl_band_entry_real_devices(gpu, synth, oracle):
 
             def work(r):
                 try:
-                    torch.cuda.set_device(r)
+                    assert hip_rt.hipSetDevice(r) == 0
                     r0, r1 = gpu.band_rows(hb, n, r)
                     parts[r] = gpu.do_quantsmooth_band([c[r0:r1] for c in j["coefs"]], j["quants"], flags, niter, r, n, comms[r], **kw)
                 except Exception as ex:  # noqa: BLE001
