@@ -194,3 +194,44 @@ def test_full_8192_420_q6_n5_every_block_vs_reference(gpu, pkg, truth):
     del one
     many = gpu.do_quantsmooth(coefs, quants, flags, niter, devices=[0] * 8, **kw)
     assert_same_result(many, want, "qs_hip_do_quantsmooth_sharded over 8 logical devices")
+
+
+def test_32768_luma_beyond_the_baseline_sizes(gpu, pkg, truth):
+    """Four times the largest BASELINE plane: 32768 x 32768 luma (16,777,216 blocks, 2 GiB of coefficients; libjpeg's own
+    limit is 65500 x 65500), --quality 3 niter 3, through the job layer (the plane travels as pipelined halo bands) and over
+    8 logical devices on both band schedules.  The reference would need minutes for the whole plane, so it runs on crops:
+    16 windows of 8 block rows -- the top, the bottom and 14 seeded random positions -- each with niter + 1 margin rows
+    (a block's result depends only on blocks within niter rows of it); the three routes must agree on EVERY block."""
+    import torch
+    import bench
+    dev = torch.device("cuda:0")
+    tile, quant = bench.synth_input_gpu(torch, pkg, 8192, 50, dev)
+    coef = np.tile(tile.cpu().numpy(), (4, 4, 1))            # seams: real neighbours, nothing special-cased
+    del tile
+    torch.cuda.empty_cache()
+    assert coef.shape == (4096, 4096, 64)
+    flags, niter, m = 0, 3, 4
+    t0 = time.time()
+    one = gpu.do_quantsmooth([coef], [quant], flags, niter)
+    print(f"[info] 32768^2 q3 through qs_hip_do_quantsmooth: {time.time() - t0:.2f} s (incl. the 2 GiB input copy of the binding)")
+    assert one["ret"] == 0
+    got = one["coefs"][0]
+    rng = np.random.default_rng(32768)
+    starts = [0, 4096 - 8] + [int(v) for v in rng.integers(8, 4096 - 16, 14)]
+    bad = 0
+    for a in starts:
+        lo, hi = max(0, a - m), min(4096, a + 8 + m)
+        want = truth.do_quantsmooth([np.ascontiguousarray(coef[lo:hi])], [quant], flags, niter, threads=0)["coefs"][0][a - lo:a - lo + 8]
+        bad += int((got[a:a + 8] != want).any(axis=2).sum())
+    assert bad == 0, f"{bad} blocks differ from the reference in the 16 checked windows"
+    g = got.astype(np.int32)
+    assert np.abs(g).max() <= 1023
+    for sched in (0, 1):
+        gpu.set_shard_schedule(sched)
+        try:
+            many = gpu.do_quantsmooth([coef], [quant], flags, niter, devices=[0] * 8)
+        finally:
+            gpu.set_shard_schedule(-1)
+        assert many["ret"] == 0
+        assert np.array_equal(many["coefs"][0], got), f"8 logical devices, schedule {sched}: differs from the one-device result"
+        del many
