@@ -235,3 +235,35 @@ def test_32768_luma_beyond_the_baseline_sizes(gpu, pkg, truth):
         assert many["ret"] == 0
         assert np.array_equal(many["coefs"][0], got), f"8 logical devices, schedule {sched}: differs from the one-device result"
         del many
+
+
+def test_65500_luma_the_largest_jpeg(gpu, pkg, truth):
+    """The largest image a JPEG file can hold: 65500 x 65500 (8188 x 8188 = 67,043,344 blocks, 8.0 GiB of coefficients),
+    luma, --quality 3 niter 3, through qs_hip_do_quantsmooth on one device.  Reference on 10 windows of 8 block rows (top,
+    bottom, 8 seeded random positions), each over the full width; every coefficient inside its interval or clamped."""
+    import torch
+    import bench
+    dev = torch.device("cuda:0")
+    tile, quant = bench.synth_input_gpu(torch, pkg, 8192, 50, dev)
+    coef = np.ascontiguousarray(np.tile(tile.cpu().numpy(), (8, 8, 1))[:8188, :8188])
+    del tile
+    torch.cuda.empty_cache()
+    flags, niter, m = 0, 3, 4
+    t0 = time.time()
+    one = gpu.do_quantsmooth([coef], [quant], flags, niter, image_size=(65500, 65500))
+    print(f"[info] 65500^2 q3 through qs_hip_do_quantsmooth: {time.time() - t0:.2f} s (incl. the 8 GiB input copy of the binding)")
+    assert one["ret"] == 0
+    got = one["coefs"][0]
+    rng = np.random.default_rng(65500)
+    bad = 0
+    for a in [0, 8188 - 8] + [int(v) for v in rng.integers(8, 8188 - 16, 8)]:
+        lo, hi = max(0, a - m), min(8188, a + 8 + m)
+        want = truth.do_quantsmooth([np.ascontiguousarray(coef[lo:hi])], [quant], flags, niter, threads=0)["coefs"][0][a - lo:a - lo + 8]
+        bad += int((got[a:a + 8] != want).any(axis=2).sum())
+    assert bad == 0, f"{bad} blocks differ from the reference in the 10 checked windows"
+    q = quant.astype(np.int32)
+    for r in range(0, 8188, 1024):                            # (in slices: int32 copies of the whole plane would be 34 GB)
+        g = got[r:r + 1024].astype(np.int32)
+        deq = coef[r:r + 1024].astype(np.int32) * q
+        assert np.abs(g).max() <= 1023
+        assert ((np.abs(g - deq) <= q // 2) | (np.abs(g) == 1023)).all()
